@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-point updates/s of the 3-D 256^3 O(8) acoustic stencil.
+
+One "step" = one full shot of BASELINE.json configs[3] (256^3 constant velocity,
+1000 time steps, O(8), fp32) through fwi_forward() on one MI355X.  With N > 1
+(launched by torch.distributed.run, one process per GPU) every rank runs its
+own shot per step -- shots are independent -- followed by the path's one real
+exchange, an RCCL all-reduce of the model-sized gradient accumulator; the
+reported value is the aggregate over ranks.  torch is used only for the
+rendezvous / barrier / max-over-ranks (gloo); the data path is HIP + RCCL
+behind the C-ABI.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_UPDATE = 16        # read u_cur, u_prev, C; write u_next (fp32)
+
+
+def cpu_baseline(w, sample_steps):
+    """The oracle's OpenMP C port (fp64) on the same grid for the first `sample_steps` steps."""
+    from oracle.c_oracle import CPropagator
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    wav = w.wavelet(np.float64)[:sample_steps]
+    p.forward(w.src_idx, wav[:2], w.rec_idx, save=False)  # warm-up / page-in
+    t0 = time.perf_counter()
+    p.forward(w.src_idx, wav, w.rec_idx, save=False)
+    el = time.perf_counter() - t0
+    return {"value": int(np.prod(w.shape)) * sample_steps / el / 1e9, "unit": "Gpts/s", "cores": cores,
+            "kind": "port",
+            "sample": "same %s grid, first %d of %d time steps, fp64 OpenMP C port of the build's oracle "
+                      "(the reference has no such path), %.1f s" % ("x".join(map(str, w.shape)),
+                                                                    sample_steps, w.nt, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=256, help="cube edge (256 = BASELINE config)")
+    ap.add_argument("--nt", type=int, default=1000)
+    ap.add_argument("--npml", type=int, default=0)
+    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--cpu-steps", type=int, default=60, help="time steps of the CPU baseline sample; 0 = skip")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from full_waveform_inversion_amd import Engine, workloads
+
+    w = workloads.cfg4(args.grid / 256.0, npml=args.npml)
+    w.nt = args.nt
+    wav = w.wavelet()
+    model = w.c.astype(np.float32)
+    e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local, kernel=args.kernel,
+               zchunk=args.zchunk)
+    e.set_model(model)
+    if world > 1:
+        ids = [Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        e.comm_init(rank, world, ids[0])
+
+    def step():
+        e.forward(None, (w.src_idx, wav), w.rec_idx, save=False)
+        ms = e.last_loop_ms()
+        if world > 1:
+            e.allreduce_gradient()  # the shot loop's one exchange (sum of per-rank gradients)
+        return ms
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    e.synchronize()
+    t0 = time.perf_counter()
+    loop_ms = [step() for _ in range(args.steps)]
+    e.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+
+    if rank == 0:
+        npts = int(np.prod(w.shape))
+        updates = npts * w.nt
+        value = world * args.steps * updates / el / 1e9
+        kern_us = 1e3 * float(np.mean(loop_ms)) / w.nt  # avg launch-to-launch time of the step kernel
+        achieved = BYTES_PER_UPDATE * npts / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic",
+            "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[3]: 3-D %s constant velocity, 1 shot/GPU/step, %d time steps, "
+                                   "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
+                       "kernel": e.kernel_name, "parallelism": "shot-parallel x%d" % world,
+                       "exchange": "rccl allreduce of the gradient accumulator per step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_avg_us": round(kern_us, 2),
+                         "note": "algorithmic 16 B/update x %d updates per launch / HIP-event time of the "
+                                 "%d-launch loop; working set 3 x %d MiB" % (npts, w.nt, npts * 4 >> 20)},
+        }
+        if args.cpu_steps > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
+        print(json.dumps(out))
+    e.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

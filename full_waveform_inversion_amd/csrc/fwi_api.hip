@@ -1,0 +1,645 @@
+// C-ABI of the engine (include/fwi.h): context, device memory, time loops,
+// RCCL exchange.  Host-side runtime only; the arithmetic is in fwi_kernels.hip.
+//
+// No reference counterpart (the reference has neither a native layer nor this
+// path); the entry points are the ones BASELINE.json's
+// north_star names.  The time loop mirrors oracle/fwi_oracle.py::_propagate
+// one-to-one so the parity tests can compare every intermediate.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fwi.h"
+#include "fwi_kernels.h"
+
+using namespace fwi;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const double COEF2[] = {-2.0, 1.0};
+const double COEF4[] = {-5.0 / 2.0, 4.0 / 3.0, -1.0 / 12.0};
+const double COEF8[] = {-205.0 / 72.0, 8.0 / 5.0, -1.0 / 5.0, 8.0 / 315.0, -1.0 / 560.0};
+
+std::string vformat(const char *fmt, va_list ap) {
+    char buf[512];
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    return buf;
+}
+
+}  // namespace
+
+struct fwi_ctx {
+    fwi_config cfg;
+    GridDesc gd;
+    int kernel = K_POINT;
+    StreamTuning tune{8, 0};
+    size_t esize = 4;  // bytes per element
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_loop_time = false;
+
+    // device fields
+    void *u[2] = {nullptr, nullptr};  // padded wavefields (ping-pong)
+    void *C = nullptr;                // padded dt^2 c^2
+    void *c_dev = nullptr;            // compact velocity
+    void *dz = nullptr, *dy = nullptr, *dx = nullptr;
+    void *q_store = nullptr;  // nt_max x npts forward terms
+    void *g_acc = nullptr;    // compact gradient accumulator
+    void *g_out = nullptr;    // compact scratch for fwi_gradient
+    double *red = nullptr;    // reduction scalars
+
+    // host copies
+    std::vector<double> c_host, pz, py, px;
+    bool have_model = false;
+
+    // per-shot point sets (device) and their sizes
+    int nt = 0, nsrc = 0, nrec = 0;
+    bool have_forward = false, have_q = false;
+    void *src_p = nullptr, *src_c = nullptr, *rec_p = nullptr, *rec_c = nullptr;  // int64 idx
+    void *src_cu = nullptr, *src_cq = nullptr, *rec_cu = nullptr, *rec_cq = nullptr;  // coefs
+    void *amp = nullptr, *series = nullptr;  // (nt, ninj) injected / (nt, nrec) recorded
+    size_t cap_pts = 0, cap_amp = 0, cap_series = 0;
+
+    ncclComm_t comm = nullptr;
+    int nranks = 1;
+
+    std::string err;
+
+    int fail(int code, const char *fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        err = vformat(fmt, ap);
+        va_end(ap);
+        return code;
+    }
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? FWI_ENOMEM : FWI_EHIP, "%s: %s",   \
+                               #call, hipGetErrorString(e_));                                 \
+    } while (0)
+
+#define NCCLCHK(ctx, call)                                                                    \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess) return (ctx)->fail(FWI_ECOMM, "%s: %s", #call, ncclGetErrorString(r_)); \
+    } while (0)
+
+namespace {
+
+void profile(std::vector<double> &p, int n, int npml, double sigma_max, double dt) {
+    p.assign(n, 0.0);
+    if (npml <= 0) return;
+    for (int i = 0; i < n; ++i) {
+        double dist = std::max(0.0, std::max((double)npml - i, (double)i - (n - 1 - npml)));
+        p[i] = 0.5 * dt * sigma_max * (dist / npml) * (dist / npml);
+    }
+}
+
+template <typename T>
+int upload_vec(fwi_ctx *ctx, void *dst, const std::vector<double> &v) {
+    std::vector<T> t(v.begin(), v.end());
+    HIPCHK(ctx, hipMemcpyAsync(dst, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int ensure(fwi_ctx *ctx, void **p, size_t *cap, size_t bytes) {
+    if (*cap >= bytes && *p) return FWI_OK;
+    if (*p) HIPCHK(ctx, hipFree(*p));
+    *p = nullptr;
+    HIPCHK(ctx, hipMalloc(p, bytes ? bytes : 16));
+    *cap = bytes;
+    return FWI_OK;
+}
+
+// Translate (n, ndim) int32 grid indices into padded / compact flat indices.
+int flatten(fwi_ctx *ctx, const int32_t *idx, int n, std::vector<int64_t> &pidx,
+            std::vector<int64_t> &cidx) {
+    const GridDesc &g = ctx->gd;
+    pidx.resize(n);
+    cidx.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const int32_t *t = idx + (size_t)i * g.ndim;
+        const int z = t[0], y = (g.ndim == 3) ? t[1] : 0, x = t[g.ndim - 1];
+        if (z < 0 || z >= g.nz || y < 0 || y >= g.ny || x < 0 || x >= g.nx)
+            return ctx->fail(FWI_EINVAL, "grid index %d outside the grid", i);
+        pidx[i] = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
+        cidx[i] = ((int64_t)z * g.ny + y) * g.nx + x;
+    }
+    return FWI_OK;
+}
+
+template <typename T>
+struct Impl {
+    static StepArgs<T> base_args(fwi_ctx *ctx, int cur) {
+        StepArgs<T> a;
+        a.u_cur = (const T *)ctx->u[cur];
+        a.u_prev = (T *)ctx->u[cur ^ 1];
+        a.C = (const T *)ctx->C;
+        a.dz = (const T *)ctx->dz;
+        a.dy = (const T *)ctx->dy;
+        a.dx = (const T *)ctx->dx;
+        a.q_out = nullptr;
+        a.q_in = nullptr;
+        a.g = (T *)ctx->g_acc;
+        const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
+        for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
+        for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / (ctx->cfg.h * ctx->cfg.h));
+        a.damp = ctx->cfg.npml > 0;
+        return a;
+    }
+
+    static int set_model(fwi_ctx *ctx, const T *c) {
+        const GridDesc &g = ctx->gd;
+        ctx->c_host.resize(g.npts);
+        std::vector<T> Cpad((size_t)g.ptot, T(0));
+        const double dt2 = ctx->cfg.dt * ctx->cfg.dt;
+        for (int z = 0; z < g.nz; ++z)
+            for (int y = 0; y < g.ny; ++y) {
+                const int64_t ci = ((int64_t)z * g.ny + y) * g.nx;
+                const int64_t pi = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy;
+                for (int x = 0; x < g.nx; ++x) {
+                    const double cv = (double)c[ci + x];
+                    if (!(cv > 0.0) || !std::isfinite(cv))
+                        return ctx->fail(FWI_EINVAL, "velocity must be finite and > 0");
+                    ctx->c_host[ci + x] = cv;
+                    Cpad[pi + x] = (T)(dt2 * cv * cv);
+                }
+            }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->C, Cpad.data(), (size_t)g.ptot * sizeof(T),
+                                   hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, c, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->have_model = true;
+        ctx->have_forward = false;
+        return FWI_OK;
+    }
+
+    // coefficient of an injected amplitude in u (A*C*scale) and in q (C*scale)
+    static void point_coefs(fwi_ctx *ctx, const int32_t *idx, int n, double scale, std::vector<T> &cu,
+                            std::vector<T> &cq) {
+        const GridDesc &g = ctx->gd;
+        const double dt2 = ctx->cfg.dt * ctx->cfg.dt;
+        cu.resize(n);
+        cq.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int32_t *t = idx + (size_t)i * g.ndim;
+            const int z = t[0], y = (g.ndim == 3) ? t[1] : 0, x = t[g.ndim - 1];
+            const double cv = ctx->c_host[((int64_t)z * g.ny + y) * g.nx + x];
+            const double d = ctx->pz[z] + ((g.ndim == 3) ? ctx->py[y] : 0.0) + ctx->px[x];
+            const double Cv = (double)(T)(dt2 * cv * cv);  // as the kernels see it
+            cq[i] = (T)(Cv * scale);
+            cu[i] = (T)(Cv * scale / (1.0 + d));
+        }
+    }
+
+    static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
+                             const int32_t *rec_idx) {
+        const GridDesc &g = ctx->gd;
+        std::vector<int64_t> sp, sc, rp, rc;
+        int rcode;
+        if ((rcode = flatten(ctx, src_idx, nsrc, sp, sc))) return rcode;
+        if ((rcode = flatten(ctx, rec_idx, nrec, rp, rc))) return rcode;
+        std::vector<T> scu, scq, rcu, rcq;
+        point_coefs(ctx, src_idx, nsrc, 1.0 / std::pow(ctx->cfg.h, g.ndim), scu, scq);
+        point_coefs(ctx, rec_idx, nrec, 1.0, rcu, rcq);
+        const size_t need = (size_t)std::max(nsrc, nrec) * 8 + 16;
+        if (ctx->cap_pts < need) {
+            void **ps[] = {&ctx->src_p, &ctx->src_c, &ctx->rec_p, &ctx->rec_c,
+                           &ctx->src_cu, &ctx->src_cq, &ctx->rec_cu, &ctx->rec_cq};
+            for (void **p : ps) {
+                if (*p) HIPCHK(ctx, hipFree(*p));
+                *p = nullptr;
+                HIPCHK(ctx, hipMalloc(p, need));
+            }
+            ctx->cap_pts = need;
+        }
+        auto up = [&](void *d, const void *h, size_t b) {
+            return b ? hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        };
+        HIPCHK(ctx, up(ctx->src_p, sp.data(), (size_t)nsrc * 8));
+        HIPCHK(ctx, up(ctx->src_c, sc.data(), (size_t)nsrc * 8));
+        HIPCHK(ctx, up(ctx->rec_p, rp.data(), (size_t)nrec * 8));
+        HIPCHK(ctx, up(ctx->rec_c, rc.data(), (size_t)nrec * 8));
+        HIPCHK(ctx, up(ctx->src_cu, scu.data(), (size_t)nsrc * sizeof(T)));
+        HIPCHK(ctx, up(ctx->src_cq, scq.data(), (size_t)nsrc * sizeof(T)));
+        HIPCHK(ctx, up(ctx->rec_cu, rcu.data(), (size_t)nrec * sizeof(T)));
+        HIPCHK(ctx, up(ctx->rec_cq, rcq.data(), (size_t)nrec * sizeof(T)));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+        return FWI_OK;
+    }
+
+    // The shared time loop (oracle: Propagator._propagate).
+    static int propagate(fwi_ctx *ctx, bool reverse, int ninj, const void *inj_p, const void *inj_c,
+                         const void *inj_cu, const void *inj_cq, int nrecd, const void *rec_p,
+                         T rec_scale, bool save_q, bool image) {
+        const GridDesc &g = ctx->gd;
+        const int nt = ctx->nt;
+        hipStream_t s = ctx->stream;
+        HIPCHK(ctx, hipMemsetAsync(ctx->u[0], 0, (size_t)g.ptot * sizeof(T), s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->u[1], 0, (size_t)g.ptot * sizeof(T), s));
+        T *q_store = (T *)ctx->q_store;
+        T *series = (T *)ctx->series;
+        const T *amp = (const T *)ctx->amp;
+        int cur = 0;
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        for (int it = 0; it < nt; ++it) {
+            const int n = reverse ? nt - 1 - it : it;
+            StepArgs<T> a = base_args(ctx, cur);
+            if (save_q) a.q_out = q_store + (size_t)n * g.npts;
+            // lagged imaging: u_cur of adjoint step n is mu^{n+2}, which pairs with q^{n+1}
+            if (image && n + 1 < nt) a.q_in = q_store + (size_t)(n + 1) * g.npts;
+            HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, s));
+            HIPCHK(ctx, launch_inject<T>((T *)ctx->u[cur ^ 1], a.q_out, (const int64_t *)inj_p,
+                                         (const int64_t *)inj_c, (const T *)inj_cu, (const T *)inj_cq,
+                                         amp + (size_t)n * ninj, ninj, s));
+            HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur ^ 1], (const int64_t *)rec_p,
+                                         series + (size_t)n * nrecd, rec_scale, nrecd, s));
+            cur ^= 1;
+        }
+        if (image)  // the last pairing: mu^1 with q^0
+            HIPCHK(ctx, launch_image<T>(g, (const T *)ctx->u[cur], q_store, (T *)ctx->g_acc, s));
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->have_loop_time = true;
+        return FWI_OK;
+    }
+
+    static int forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx,
+                       const T *wavelet, int32_t nrec, const int32_t *rec_idx, int32_t save,
+                       T *seis_out) {
+        const GridDesc &g = ctx->gd;
+        int rc;
+        if ((rc = upload_points(ctx, nsrc, src_idx, nrec, rec_idx))) return rc;
+        if (save && !ctx->q_store) {
+            const size_t bytes = (size_t)ctx->cfg.nt_max * g.npts * sizeof(T);
+            size_t fr = 0, tot = 0;
+            HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
+            if (bytes > fr)
+                return ctx->fail(FWI_ENOMEM,
+                                 "forward-term store needs %.1f GiB (nt_max=%d) but only %.1f GiB are free",
+                                 bytes / 1073741824.0, ctx->cfg.nt_max, fr / 1073741824.0);
+            HIPCHK(ctx, hipMalloc(&ctx->q_store, bytes));
+        }
+        if ((rc = ensure(ctx, &ctx->amp, &ctx->cap_amp,
+                         (size_t)nt * std::max(nsrc, nrec) * sizeof(T))))
+            return rc;
+        if ((rc = ensure(ctx, &ctx->series, &ctx->cap_series,
+                         (size_t)nt * std::max(nsrc, nrec) * sizeof(T))))
+            return rc;
+        ctx->nt = nt;
+        ctx->nsrc = nsrc;
+        ctx->nrec = nrec;
+        ctx->have_forward = false;
+        ctx->have_q = false;
+        if (nsrc)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, wavelet, (size_t)nt * nsrc * sizeof(T),
+                                       hipMemcpyHostToDevice, ctx->stream));
+        rc = propagate(ctx, false, nsrc, ctx->src_p, ctx->src_c, ctx->src_cu, ctx->src_cq, nrec,
+                       ctx->rec_p, T(1), save != 0, false);
+        if (rc) return rc;
+        if (nrec && seis_out)
+            HIPCHK(ctx, hipMemcpyAsync(seis_out, ctx->series, (size_t)nt * nrec * sizeof(T),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->have_forward = true;
+        ctx->have_q = save != 0;
+        return FWI_OK;
+    }
+
+    static int adjoint(fwi_ctx *ctx, const T *residual, int32_t image, T *adj_src_out) {
+        const GridDesc &g = ctx->gd;
+        if (ctx->nrec)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, residual, (size_t)ctx->nt * ctx->nrec * sizeof(T),
+                                       hipMemcpyHostToDevice, ctx->stream));
+        const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
+        int rc = propagate(ctx, true, ctx->nrec, ctx->rec_p, ctx->rec_c, ctx->rec_cu, ctx->rec_cq,
+                           ctx->nsrc, ctx->src_p, rs, false, image != 0);
+        if (rc) return rc;
+        if (adj_src_out && ctx->nsrc)
+            HIPCHK(ctx, hipMemcpyAsync(adj_src_out, ctx->series, (size_t)ctx->nt * ctx->nsrc * sizeof(T),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return FWI_OK;
+    }
+
+    static int gradient(fwi_ctx *ctx, int32_t wrt, T *out) {
+        const GridDesc &g = ctx->gd;
+        const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
+        HIPCHK(ctx, launch_finalize_gradient<T>((const T *)ctx->g_acc, (const T *)ctx->c_dev,
+                                                (T *)ctx->g_out, scale, wrt == FWI_WRT_VELOCITY,
+                                                g.npts, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->g_out, (size_t)g.npts * sizeof(T), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return FWI_OK;
+    }
+
+    static int dot(fwi_ctx *ctx, const T *a, const T *b, int64_t n, double *out) {
+        void *da = nullptr, *db = nullptr;
+        HIPCHK(ctx, hipMalloc(&da, (size_t)n * sizeof(T)));
+        hipError_t e = hipMalloc(&db, (size_t)n * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipFree(da);
+            return ctx->fail(FWI_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+        }
+        int rc = FWI_OK;
+        do {
+            if ((e = hipMemcpyAsync(da, a, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream))) break;
+            if ((e = hipMemcpyAsync(db, b, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream))) break;
+            if ((e = hipMemsetAsync(ctx->red, 0, sizeof(double), ctx->stream))) break;
+            if ((e = launch_dot<T>((const T *)da, (const T *)db, n, ctx->red, ctx->stream))) break;
+            if ((e = hipMemcpyAsync(out, ctx->red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream))) break;
+            e = hipStreamSynchronize(ctx->stream);
+        } while (0);
+        if (e != hipSuccess) rc = ctx->fail(FWI_EHIP, "fwi_dot: %s", hipGetErrorString(e));
+        (void)hipFree(da);
+        (void)hipFree(db);
+        return rc;
+    }
+};
+
+int create_impl(fwi_ctx *ctx) {
+    const fwi_config &c = ctx->cfg;
+    const GridDesc &g = ctx->gd;
+    const size_t es = ctx->esize;
+    HIPCHK(ctx, hipSetDevice(c.device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev0));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(ctx, hipMalloc(&ctx->u[i], (size_t)g.ptot * es));
+        HIPCHK(ctx, hipMemsetAsync(ctx->u[i], 0, (size_t)g.ptot * es, ctx->stream));
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->C, (size_t)g.ptot * es));
+    HIPCHK(ctx, hipMemsetAsync(ctx->C, 0, (size_t)g.ptot * es, ctx->stream));
+    HIPCHK(ctx, hipMalloc(&ctx->c_dev, (size_t)g.npts * es));
+    HIPCHK(ctx, hipMalloc(&ctx->g_acc, (size_t)g.npts * es));
+    HIPCHK(ctx, hipMemsetAsync(ctx->g_acc, 0, (size_t)g.npts * es, ctx->stream));
+    HIPCHK(ctx, hipMalloc(&ctx->g_out, (size_t)g.npts * es));
+    HIPCHK(ctx, hipMalloc(&ctx->dz, (size_t)g.nz * es));
+    HIPCHK(ctx, hipMalloc(&ctx->dy, (size_t)g.ny * es));
+    HIPCHK(ctx, hipMalloc(&ctx->dx, (size_t)g.nx * es));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->red, 64));
+    double sm = c.sigma_max;
+    profile(ctx->pz, g.nz, c.npml, sm, c.dt);
+    profile(ctx->px, g.nx, c.npml, sm, c.dt);
+    if (g.ndim == 3) profile(ctx->py, g.ny, c.npml, sm, c.dt); else ctx->py.assign(1, 0.0);
+    int rc;
+    if (c.dtype == FWI_F32) {
+        if ((rc = upload_vec<float>(ctx, ctx->dz, ctx->pz))) return rc;
+        if ((rc = upload_vec<float>(ctx, ctx->dy, ctx->py))) return rc;
+        if ((rc = upload_vec<float>(ctx, ctx->dx, ctx->px))) return rc;
+    } else {
+        if ((rc = upload_vec<double>(ctx, ctx->dz, ctx->pz))) return rc;
+        if ((rc = upload_vec<double>(ctx, ctx->dy, ctx->py))) return rc;
+        if ((rc = upload_vec<double>(ctx, ctx->dx, ctx->px))) return rc;
+    }
+    return FWI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fwi_abi_version(void) { return FWI_ABI_VERSION; }
+
+int fwi_device_count(int32_t *n_out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (n_out) *n_out = (e == hipSuccess) ? n : 0;
+    return (e == hipSuccess && n > 0) ? FWI_OK : FWI_EHIP;
+}
+
+const char *fwi_last_error(const fwi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char *fwi_kernel_name(const fwi_ctx *ctx) {
+    if (!ctx) return "";
+    return ctx->kernel == K_STREAM ? "step3d_stream" : "step_point";
+}
+
+int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
+    if (!cfg || !out) {
+        g_create_error = "fwi_create: null argument";
+        return FWI_EINVAL;
+    }
+    *out = nullptr;
+    auto bad = [&](const char *m) {
+        g_create_error = std::string("fwi_create: ") + m;
+        return FWI_EINVAL;
+    };
+    if (cfg->struct_size != (int32_t)sizeof(fwi_config)) return bad("struct_size mismatch (ABI)");
+    if (cfg->ndim != 2 && cfg->ndim != 3) return bad("ndim must be 2 or 3");
+    if (cfg->nz < 1 || cfg->nx < 1 || (cfg->ndim == 3 && cfg->ny < 1)) return bad("empty grid");
+    if (cfg->order != 2 && cfg->order != 4 && cfg->order != 8) return bad("order must be 2, 4 or 8");
+    if (cfg->nt_max < 1) return bad("nt_max must be >= 1");
+    if (cfg->npml < 0) return bad("npml must be >= 0");
+    if (!(cfg->h > 0) || !(cfg->dt > 0)) return bad("h and dt must be > 0");
+    if (cfg->dtype != FWI_F32 && cfg->dtype != FWI_F64) return bad("dtype must be FWI_F32 or FWI_F64");
+    if (cfg->npml > 0 && !(cfg->sigma_max >= 0)) return bad("sigma_max must be >= 0 when npml > 0");
+    if (cfg->kernel < FWI_KERNEL_AUTO || cfg->kernel > FWI_KERNEL_STREAM) return bad("unknown kernel id");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
+        return FWI_EHIP;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
+
+    fwi_ctx *ctx = new (std::nothrow) fwi_ctx;
+    if (!ctx) {
+        g_create_error = "fwi_create: out of host memory";
+        return FWI_ENOMEM;
+    }
+    ctx->cfg = *cfg;
+    ctx->gd = make_grid(cfg->ndim, cfg->nz, cfg->ny, cfg->nx, cfg->order);
+    ctx->esize = cfg->dtype == FWI_F32 ? 4 : 8;
+    const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
+    if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
+        delete ctx;
+        return bad("STREAM kernel needs a 3-D fp32 grid with nx % 4 == 0");
+    }
+    ctx->kernel = (cfg->kernel == FWI_KERNEL_POINT || !can_stream) ? K_POINT : K_STREAM;
+    if (ctx->kernel == K_STREAM) {
+        ctx->tune = stream_default_tuning(ctx->gd);
+        if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
+        if (const char *ty = getenv("FWI_STREAM_TY")) {  // tuning hook: rows per workgroup
+            const int v = atoi(ty);
+            if (v == 4 || v == 8 || v == 16) ctx->tune.ty = v;
+        }
+    }
+    int rc = create_impl(ctx);
+    if (rc) {
+        g_create_error = "fwi_create: " + ctx->err;
+        fwi_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return FWI_OK;
+}
+
+void fwi_destroy(fwi_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
+                    ctx->g_acc, ctx->g_out, ctx->red, ctx->src_p, ctx->src_c, ctx->rec_p, ctx->rec_c,
+                    ctx->src_cu, ctx->src_cq, ctx->rec_cu, ctx->rec_cq, ctx->amp, ctx->series};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+#define DISPATCH(ctx, expr32, expr64) ((ctx)->cfg.dtype == FWI_F32 ? (expr32) : (expr64))
+
+int fwi_set_model(fwi_ctx *ctx, const void *c_host) {
+    if (!ctx) return FWI_EINVAL;
+    if (!c_host) return ctx->fail(FWI_EINVAL, "fwi_set_model: null model");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::set_model(ctx, (const float *)c_host),
+                    Impl<double>::set_model(ctx, (const double *)c_host));
+}
+
+int fwi_forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx, const void *wavelet,
+                int32_t nrec, const int32_t *rec_idx, int32_t save, void *seis_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->have_model) return ctx->fail(FWI_ESTATE, "fwi_forward: call fwi_set_model first");
+    if (nt < 1 || nt > ctx->cfg.nt_max)
+        return ctx->fail(FWI_EINVAL, "fwi_forward: nt=%d outside [1, nt_max=%d]", nt, ctx->cfg.nt_max);
+    if (nsrc < 0 || nrec < 0) return ctx->fail(FWI_EINVAL, "fwi_forward: negative point count");
+    if ((nsrc && (!src_idx || !wavelet)) || (nrec && (!rec_idx || !seis_out)))
+        return ctx->fail(FWI_EINVAL, "fwi_forward: null buffer");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx,
+                    Impl<float>::forward(ctx, nt, nsrc, src_idx, (const float *)wavelet, nrec, rec_idx,
+                                         save, (float *)seis_out),
+                    Impl<double>::forward(ctx, nt, nsrc, src_idx, (const double *)wavelet, nrec,
+                                          rec_idx, save, (double *)seis_out));
+}
+
+int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->have_forward) return ctx->fail(FWI_ESTATE, "fwi_adjoint: no forward run to adjoin");
+    if (image && !ctx->have_q)
+        return ctx->fail(FWI_ESTATE, "fwi_adjoint: imaging needs fwi_forward(save=1) first");
+    if (ctx->nrec && !residual) return ctx->fail(FWI_EINVAL, "fwi_adjoint: null residual");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::adjoint(ctx, (const float *)residual, image, (float *)adj_src_out),
+                    Impl<double>::adjoint(ctx, (const double *)residual, image, (double *)adj_src_out));
+}
+
+int fwi_gradient(fwi_ctx *ctx, int32_t wrt, void *g_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!g_out) return ctx->fail(FWI_EINVAL, "fwi_gradient: null output");
+    if (wrt != FWI_WRT_VELOCITY && wrt != FWI_WRT_SLOWNESS2)
+        return ctx->fail(FWI_EINVAL, "fwi_gradient: unknown parametrisation %d", wrt);
+    if (!ctx->have_model) return ctx->fail(FWI_ESTATE, "fwi_gradient: no model set");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::gradient(ctx, wrt, (float *)g_out),
+                    Impl<double>::gradient(ctx, wrt, (double *)g_out));
+}
+
+int fwi_gradient_reset(fwi_ctx *ctx) {
+    if (!ctx) return FWI_EINVAL;
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipMemsetAsync(ctx->g_acc, 0, (size_t)ctx->gd.npts * ctx->esize, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_dot(fwi_ctx *ctx, const void *a, const void *b, int64_t n, double *out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!a || !b || !out || n < 0) return ctx->fail(FWI_EINVAL, "fwi_dot: bad argument");
+    if (n == 0) {
+        *out = 0.0;
+        return FWI_OK;
+    }
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::dot(ctx, (const float *)a, (const float *)b, n, out),
+                    Impl<double>::dot(ctx, (const double *)a, (const double *)b, n, out));
+}
+
+int fwi_comm_unique_id(void *id_out) {
+    static_assert(sizeof(ncclUniqueId) == FWI_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return FWI_EINVAL;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return FWI_ECOMM;
+    memcpy(id_out, &id, sizeof id);
+    return FWI_OK;
+}
+
+int fwi_comm_init(fwi_ctx *ctx, int32_t rank, int32_t nranks, const void *id) {
+    if (!ctx) return FWI_EINVAL;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks)
+        return ctx->fail(FWI_EINVAL, "fwi_comm_init: bad rank %d of %d", rank, nranks);
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->comm) {
+        (void)ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHK(ctx, ncclCommInitRank(&ctx->comm, nranks, uid, rank));
+    ctx->nranks = nranks;
+    return FWI_OK;
+}
+
+int fwi_allreduce_gradient(fwi_ctx *ctx) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->comm) return ctx->fail(FWI_ESTATE, "fwi_allreduce_gradient: call fwi_comm_init first");
+    (void)hipSetDevice(ctx->cfg.device);
+    NCCLCHK(ctx, ncclAllReduce(ctx->g_acc, ctx->g_acc, (size_t)ctx->gd.npts,
+                               ctx->cfg.dtype == FWI_F32 ? ncclFloat32 : ncclFloat64, ncclSum, ctx->comm,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_allreduce_f64(fwi_ctx *ctx, double *vals, int32_t n) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->comm) return ctx->fail(FWI_ESTATE, "fwi_allreduce_f64: call fwi_comm_init first");
+    if (!vals || n < 1 || n > 8) return ctx->fail(FWI_EINVAL, "fwi_allreduce_f64: n must be in [1, 8]");
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->red, vals, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(ctx, ncclAllReduce(ctx->red, ctx->red, (size_t)n, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(vals, ctx->red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out) {
+    if (!ctx || !ms_out) return FWI_EINVAL;
+    if (!ctx->have_loop_time) return ctx->fail(FWI_ESTATE, "fwi_last_loop_ms: no time loop has run");
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = ms;
+    return FWI_OK;
+}
+
+int fwi_synchronize(fwi_ctx *ctx) {
+    if (!ctx) return FWI_EINVAL;
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Internal launch interface between the C-ABI (fwi_api.hip) and the gfx950
+// kernels (fwi_kernels.hip).  Not part of the public boundary (include/fwi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fwi {
+
+// Layout halo of every padded field: 4 cells on each side of every stencil
+// axis, whatever the order (4 floats = 16 B keeps interior rows float4-aligned).
+constexpr int HALO = 4;
+// Padded extents are rounded so any tile of the stream kernels stays inside
+// the allocation: x to XALIGN cells, y to YALIGN rows.
+constexpr int XALIGN = 256;
+constexpr int YALIGN = 16;
+
+// Padded field geometry.  Element (z, y, x) of the interior lives at
+// off0 + z*sz + y*sy + x.  2-D grids are ny = 1 with no y halo (sz == sy).
+struct GridDesc {
+    int ndim, nz, ny, nx;
+    int r;           // stencil radius (order / 2)
+    int64_t sy, sz;  // padded strides in elements (x stride is 1)
+    int64_t off0;    // padded offset of interior point (0, 0, 0)
+    int64_t ptot;    // elements of one padded field
+    int64_t npts;    // nz * ny * nx
+};
+
+GridDesc make_grid(int ndim, int nz, int ny, int nx, int order);
+
+template <typename T>
+struct StepArgs {
+    const T *u_cur;  // u^n, padded, read with halo
+    T *u_prev;       // in: u^{n-1}; out: u^{n+1} (same padded buffer)
+    const T *C;      // dt^2 c^2, padded
+    const T *dz, *dy, *dx;  // per-axis damping d = sigma dt / 2 (lengths nz, ny, nx)
+    T *q_out;        // compact (npts) forward term of this step, or nullptr
+    const T *q_in;   // compact forward term to correlate u_cur with, or nullptr
+    T *g;            // compact gradient accumulator (used with q_in)
+    T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
+    int damp;        // npml > 0
+};
+
+enum StencilKernel { K_POINT = 1, K_STREAM = 2 };
+
+struct StreamTuning {
+    int ty;      // rows per workgroup (4, 8 or 16)
+    int zchunk;  // planes marched per workgroup
+};
+
+// True when the stream kernel supports this grid / dtype.
+bool stream_supported(const GridDesc &g, bool is_f32);
+StreamTuning stream_default_tuning(const GridDesc &g);
+
+template <typename T>
+hipError_t launch_step(int kernel, const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t,
+                       hipStream_t s);
+
+// u[pidx[i]] += coef_u[i] * amp[i];  q[cidx[i]] += coef_q[i] * amp[i] (if q != nullptr)
+template <typename T>
+hipError_t launch_inject(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
+                         const T *coef_q, const T *amp, int n, hipStream_t s);
+// out[i] = u[pidx[i]] * scale
+template <typename T>
+hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n, hipStream_t s);
+// g[i] += u(center of point i) * q[i] over the whole grid (last imaging step)
+template <typename T>
+hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipStream_t s);
+// out[i] = gacc[i] * scale * (wrt_velocity ? -2 / c[i]^3 : 1)
+template <typename T>
+hipError_t launch_finalize_gradient(const T *gacc, const T *c, T *out, double scale,
+                                    int wrt_velocity, int64_t n, hipStream_t s);
+// *out += sum a[i] * b[i]  (out must be zeroed by the caller)
+template <typename T>
+hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);
+
+}  // namespace fwi

@@ -1,0 +1,483 @@
+// gfx950 (MI355X, CDNA4) kernels of the acoustic time-stepping path.
+//
+// No reference counterpart: the reference has no stencil / PML / adjoint /
+// imaging code; the scheme is the build-defined one stated at
+// the top of oracle/fwi_oracle.py.  All kernels are HBM-bandwidth bound
+// (~2.4 flop/B), so no MFMA: the work here is coalesced 16 B/lane streams,
+// an LDS-staged xy halo tile, a register queue along z and wave64 shuffles
+// for the reductions.
+//
+// Numerics: the Laplacian is evaluated in difference form
+//     L u = sum_k c_k * ( sum_axes (u[+k] + u[-k]) - 2 D u )
+// which is algebraically the centred star but keeps fp32 round-off ~30x lower
+// over thousands of steps than the coefficient form (the rounded coefficients
+// of the latter do not sum to zero, which acts as a spurious mass term).
+#include "fwi_kernels.h"
+
+#include <algorithm>
+
+namespace fwi {
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
+    GridDesc g;
+    g.ndim = ndim;
+    g.nz = nz;
+    g.ny = (ndim == 3) ? ny : 1;
+    g.nx = nx;
+    g.r = order / 2;
+    const int hy = (ndim == 3) ? HALO : 0;
+    g.sy = HALO + round_up(nx, XALIGN) + HALO;
+    const int64_t py = (ndim == 3) ? HALO + round_up(g.ny, YALIGN) + HALO : 1;
+    g.sz = g.sy * py;
+    g.off0 = (int64_t)HALO * g.sz + (int64_t)hy * g.sy + HALO;
+    g.ptot = g.sz * (int64_t)(nz + 2 * HALO);
+    g.npts = (int64_t)nz * g.ny * nx;
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// POINT kernel: one thread per grid point, all 4r+... neighbours straight from
+// global memory (L1/L2 absorb the re-reads).  Generic in dtype, order and
+// dimension; the fallback for shapes the stream kernel does not take and the
+// on-device cross-check of it.
+// ---------------------------------------------------------------------------
+template <typename T, int R, int NDIM, bool SAVE_Q, bool IMAGE>
+__global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    int y, z;
+    if (NDIM == 3) {
+        y = blockIdx.y * 4 + threadIdx.y;
+        z = blockIdx.z;
+    } else {
+        y = 0;
+        z = blockIdx.y * 4 + threadIdx.y;
+    }
+    if (x >= g.nx || y >= g.ny || z >= g.nz) return;
+    const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
+    const T *u = a.u_cur + p;
+    const T uc = u[0];
+    T lap = T(0);
+#pragma unroll
+    for (int k = R; k >= 1; --k) {
+        T t = (u[-k] + u[k]) + (u[-(int64_t)k * g.sz] + u[(int64_t)k * g.sz]);
+        if (NDIM == 3) t += (u[-(int64_t)k * g.sy] + u[(int64_t)k * g.sy]);
+        t = fma(T(-2 * NDIM), uc, t);
+        lap = fma(a.ck[k], t, lap);
+    }
+    const T q = a.C[p] * lap;
+    const T up = a.u_prev[p];
+    T un;
+    if (a.damp) {
+        T d = a.dz[z] + a.dx[x];
+        if (NDIM == 3) d += a.dy[y];
+        un = (T(2) * uc - (T(1) - d) * up + q) / (T(1) + d);
+    } else {
+        un = (T(2) * uc - up) + q;
+    }
+    a.u_prev[p] = un;
+    const int64_t ci = ((int64_t)z * g.ny + y) * g.nx + x;
+    if (SAVE_Q) a.q_out[ci] = q;
+    if (IMAGE) a.g[ci] += uc * a.q_in[ci];
+}
+
+// ---------------------------------------------------------------------------
+// STREAM kernel (3-D, fp32): a workgroup of 64 x TY threads owns a 256 x TY
+// (x, y) tile and marches `zchunk` planes in z.  Each thread owns one float4
+// (4 consecutive x) per plane: every global access is a coalesced 16 B/lane
+// stream, a wave covers 1 KiB of one row.
+//   z neighbours : 2r+1 deep register queue, fed one plane ahead of use.
+//   y neighbours : the current plane's TY + 2r rows staged in LDS (double
+//                  buffered, so ONE barrier per plane); the 2r halo rows are
+//                  fetched one plane ahead by the waves themselves.
+//   x neighbours : the row's left/right float4 read back from the same LDS
+//                  row (lanes 0 / 63 add the 16 B edge pieces).
+// Algorithmic traffic 16 B/point (u_cur, u_prev, C in; u_next out); the halo
+// re-reads ((TY+2r)/TY in y, (zchunk+2r)/zchunk in z) are L2 / Infinity Cache
+// traffic.  Blocks are renumbered so each XCD (private 4 MiB L2) owns a
+// contiguous slab of tiles and shares those halo rows on chip.
+// ---------------------------------------------------------------------------
+struct alignas(16) f4 {
+    float v[4];
+};
+
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const f4 &v) { *reinterpret_cast<f4 *>(p) = v; }
+
+constexpr int TILE_X = 256;                // floats per tile row = 64 lanes x float4
+constexpr int LROW4 = TILE_X / 4 + 2;      // LDS row in float4: [left edge][64][right edge]
+
+template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE>
+__global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, GridDesc g, int zchunk,
+                                                         int nxt, int nyt, int nblk) {
+    constexpr int LROWS = TY + 2 * R;
+    constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
+    __shared__ f4 lds[2][LROWS][LROW4];
+
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous slabs
+    const int bx = bid % nxt;
+    const int t2 = bid / nxt;
+    const int by = t2 % nyt, bz = t2 / nyt;
+    const int x0 = bx * TILE_X + 4 * lane;
+    const int y0 = by * TY, y = y0 + ty;
+    const int z0 = bz * zchunk;
+    const int z1 = min(g.nz, z0 + zchunk);
+    const bool act = (x0 < g.nx) && (y < g.ny);
+    const int64_t sz = g.sz, sy = g.sy;
+    const int zlast = g.nz + HALO - 1;  // last padded plane (interior-relative)
+
+    // Addressing: wave-uniform 64-bit plane base (SGPRs) + per-thread 32-bit
+    // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
+    // same padded layout).
+    const unsigned poff = (unsigned)(g.off0 + (int64_t)y * sy + x0);  // (z = 0, y, x0)
+    const unsigned coff = (unsigned)((int64_t)y * g.nx + x0);         // compact, z = 0
+    const int64_t cplane = (int64_t)g.ny * g.nx;
+
+    // halo rows this thread fetches: hr in [0, 2R), below (hr < R) or above the tile
+    unsigned hoff[NH];
+    int hrow[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hr = ty + i * TY;
+        const int yh = (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
+        hrow[i] = (hr < 2 * R) ? ((hr < R) ? hr : TY + hr) : -1;
+        hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + x0);
+    }
+
+    // loop-invariant xy part of the damping
+    f4 Axy, Bxy, dxy;
+    if (DAMP) {
+        const float dyv = (y < g.ny) ? a.dy[y] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = dyv + ((x0 + j < g.nx) ? a.dx[x0 + j] : 0.f);
+            dxy.v[j] = d;
+            Bxy.v[j] = 1.f - d;
+            Axy.v[j] = 1.f / (1.f + d);
+        }
+    }
+
+    // z register queue: zq[k] = plane z - R + k
+    f4 zq[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) zq[k + 1] = ld4(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
+    f4 zfront = ld4(a.u_cur + (int64_t)(z0 + R) * sz + poff);
+    f4 up = ld4(a.u_prev + (int64_t)z0 * sz + poff), Cc = ld4(a.C + (int64_t)z0 * sz + poff);
+    f4 halo[NH], edge;
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+        if (hrow[i] >= 0) halo[i] = ld4(a.u_cur + (int64_t)z0 * sz + hoff[i]);
+    // lanes 0 / 63 also carry the 16 B to the left / right of the tile row
+    const bool is_edge = (lane == 0) || (lane == 63);
+    const unsigned eoff = (lane == 0) ? poff - 4 : poff + 4;
+    const int ecol = (lane == 0) ? 0 : LROW4 - 1;
+    if (is_edge) edge = ld4(a.u_cur + (int64_t)z0 * sz + eoff);
+
+    for (int z = z0; z < z1; ++z) {
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) zq[k] = zq[k + 1];
+        zq[2 * R] = zfront;
+
+        // stage the plane's rows in LDS (double buffered: one barrier per plane)
+        f4(*L)[LROW4] = lds[z & 1];
+        L[R + ty][1 + lane] = zq[R];
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (hrow[i] >= 0) L[hrow[i]][1 + lane] = halo[i];
+        if (is_edge) L[R + ty][ecol] = edge;
+
+        // refill the consumed registers one plane ahead
+        zfront = ld4(a.u_cur + (int64_t)min(z + R + 1, zlast) * sz + poff);
+        const float *ucn = a.u_cur + (int64_t)min(z + 1, zlast) * sz;
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+            if (hrow[i] >= 0) halo[i] = ld4(ucn + hoff[i]);
+        if (is_edge) edge = ld4(ucn + eoff);
+        f4 qi, gi;
+        if (IMAGE && act) {
+            qi = ld4(a.q_in + (int64_t)z * cplane + coff);
+            gi = ld4(a.g + (int64_t)z * cplane + coff);
+        }
+        __syncthreads();
+
+        const f4 xl = L[R + ty][lane], xr = L[R + ty][lane + 2];
+        float X[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            X[j] = xl.v[j];
+            X[4 + j] = zq[R].v[j];
+            X[8 + j] = xr.v[j];
+        }
+        f4 lap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lap.v[j] = 0.f;
+#pragma unroll
+        for (int k = R; k >= 1; --k) {
+            const f4 ym = L[R + ty - k][1 + lane], yp = L[R + ty + k][1 + lane];
+            const f4 zm = zq[R - k], zp = zq[R + k];
+            const float c = a.ck[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = (X[4 + j - k] + X[4 + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
+                t = fmaf(-6.f, X[4 + j], t);
+                lap.v[j] = fmaf(c, t, lap.v[j]);
+            }
+        }
+
+        f4 A = Axy, B = Bxy;
+        if (DAMP) {
+            const float dzv = a.dz[z];
+            if (dzv != 0.f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = dxy.v[j] + dzv;
+                    B.v[j] = 1.f - d;
+                    A.v[j] = 1.f / (1.f + d);
+                }
+            }
+        }
+        f4 q, un;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q.v[j] = Cc.v[j] * lap.v[j];
+            if (DAMP)
+                un.v[j] = (fmaf(2.f, X[4 + j], -B.v[j] * up.v[j]) + q.v[j]) * A.v[j];
+            else
+                un.v[j] = (2.f * X[4 + j] - up.v[j]) + q.v[j];
+        }
+        // next plane's pointwise operands go into the registers just consumed
+        const int64_t on = (int64_t)min(z + 1, zlast) * sz;
+        up = ld4(a.u_prev + on + poff);
+        Cc = ld4(a.C + on + poff);
+        if (act) {
+            st4(a.u_prev + (int64_t)z * sz + poff, un);
+            if (SAVE_Q) st4(a.q_out + (int64_t)z * cplane + coff, q);
+            if (IMAGE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+                st4(a.g + (int64_t)z * cplane + coff, gi);
+            }
+        }
+    }
+}
+
+bool stream_supported(const GridDesc &g, bool is_f32) {
+    return is_f32 && g.ndim == 3 && (g.nx % 4 == 0) && g.nz >= 1;
+}
+
+StreamTuning stream_default_tuning(const GridDesc &g) {
+    StreamTuning t;
+    t.ty = 8;
+    // enough workgroups to fill 256 CUs twice over, but keep the z halo re-read small
+    const int64_t tiles_xy = round_up(g.nx, TILE_X) / TILE_X * (round_up(g.ny, t.ty) / t.ty);
+    int zc = g.nz;
+    while (zc > 16 && tiles_xy * ((g.nz + zc - 1) / zc) < 512) zc = (zc + 1) / 2;
+    t.zchunk = zc;
+    return t;
+}
+
+template <int R, int TY, bool DAMP>
+static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk,
+                                     hipStream_t s) {
+    const int nxt = (int)(round_up(g.nx, TILE_X) / TILE_X);
+    const int nyt = (g.ny + TY - 1) / TY;
+    const int nzc = (g.nz + zchunk - 1) / zchunk;
+    const int nblk = nxt * nyt * nzc;
+    dim3 block(64, TY), grid(nblk);
+    if (a.q_out)
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false>), grid, block, 0, s, a, g, zchunk,
+                           nxt, nyt, nblk);
+    else if (a.q_in)
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true>), grid, block, 0, s, a, g, zchunk,
+                           nxt, nyt, nblk);
+    else
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false>), grid, block, 0, s, a, g,
+                           zchunk, nxt, nyt, nblk);
+    return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, const StreamTuning &t,
+                                  hipStream_t s) {
+    const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
+    if (a.damp) {
+        switch (t.ty) {
+            case 4: return launch_stream_mode<R, 4, true>(g, a, zc, s);
+            case 16: return launch_stream_mode<R, 16, true>(g, a, zc, s);
+            default: return launch_stream_mode<R, 8, true>(g, a, zc, s);
+        }
+    }
+    switch (t.ty) {
+        case 4: return launch_stream_mode<R, 4, false>(g, a, zc, s);
+        case 16: return launch_stream_mode<R, 16, false>(g, a, zc, s);
+        default: return launch_stream_mode<R, 8, false>(g, a, zc, s);
+    }
+}
+
+template <typename T, int R, int NDIM>
+static hipError_t launch_point_mode(const GridDesc &g, const StepArgs<T> &a, hipStream_t s) {
+    dim3 block(64, 4);
+    dim3 grid((g.nx + 63) / 64, NDIM == 3 ? (g.ny + 3) / 4 : (g.nz + 3) / 4, NDIM == 3 ? g.nz : 1);
+    if (a.q_out)
+        hipLaunchKernelGGL((step_point<T, R, NDIM, true, false>), grid, block, 0, s, a, g);
+    else if (a.q_in)
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, true>), grid, block, 0, s, a, g);
+    else
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, false>), grid, block, 0, s, a, g);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_point(const GridDesc &g, const StepArgs<T> &a, hipStream_t s) {
+    if (g.ndim == 3) {
+        switch (g.r) {
+            case 1: return launch_point_mode<T, 1, 3>(g, a, s);
+            case 2: return launch_point_mode<T, 2, 3>(g, a, s);
+            default: return launch_point_mode<T, 4, 3>(g, a, s);
+        }
+    }
+    switch (g.r) {
+        case 1: return launch_point_mode<T, 1, 2>(g, a, s);
+        case 2: return launch_point_mode<T, 2, 2>(g, a, s);
+        default: return launch_point_mode<T, 4, 2>(g, a, s);
+    }
+}
+
+template <>
+hipError_t launch_step<float>(int kernel, const GridDesc &g, const StepArgs<float> &a,
+                              const StreamTuning &t, hipStream_t s) {
+    if (kernel == K_STREAM) {
+        switch (g.r) {
+            case 1: return launch_stream_r<1>(g, a, t, s);
+            case 2: return launch_stream_r<2>(g, a, t, s);
+            default: return launch_stream_r<4>(g, a, t, s);
+        }
+    }
+    return launch_point<float>(g, a, s);
+}
+
+template <>
+hipError_t launch_step<double>(int, const GridDesc &g, const StepArgs<double> &a, const StreamTuning &,
+                               hipStream_t s) {
+    return launch_point<double>(g, a, s);
+}
+
+// ---------------------------------------------------------------------------
+// Point operations: source / residual injection and receiver sampling.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void inject_kernel(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
+                              const T *coef_q, const T *amp, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const T a = amp[i];
+    atomicAdd(u + pidx[i], coef_u[i] * a);  // atomics: several points may share a node
+    if (q) atomicAdd(q + cidx[i], coef_q[i] * a);
+}
+
+template <typename T>
+__global__ void record_kernel(const T *u, const int64_t *pidx, T *out, T scale, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = u[pidx[i]] * scale;
+}
+
+template <typename T>
+hipError_t launch_inject(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
+                         const T *coef_q, const T *amp, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(inject_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, s, u, q, pidx, cidx, coef_u,
+                       coef_q, amp, n);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(record_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, s, u, pidx, out, scale, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Imaging tail, gradient scaling, dot product.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void image_kernel(GridDesc g, const T *u, const T *q, T *gacc) {
+    const int64_t rowlen = g.nx;
+    for (int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ci < g.npts;
+         ci += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = ci / rowlen;  // z * ny + y
+        const int x = (int)(ci - row * rowlen);
+        const int z = (int)(row / g.ny), y = (int)(row % g.ny);
+        const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
+        gacc[ci] += u[p] * q[ci];
+    }
+}
+
+template <typename T>
+hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (g.npts + 255) / 256));
+    hipLaunchKernelGGL(image_kernel<T>, dim3(blocks), dim3(256), 0, s, g, u, q, gacc);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void finalize_gradient_kernel(const T *gacc, const T *c, T *out, double scale,
+                                         int wrt_velocity, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double v = (double)gacc[i] * scale;
+        if (wrt_velocity) {
+            const double cc = (double)c[i];
+            v *= -2.0 / (cc * cc * cc);
+        }
+        out[i] = (T)v;
+    }
+}
+
+template <typename T>
+hipError_t launch_finalize_gradient(const T *gacc, const T *c, T *out, double scale, int wrt_velocity,
+                                    int64_t n, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(finalize_gradient_kernel<T>, dim3(blocks), dim3(256), 0, s, gacc, c, out, scale,
+                       wrt_velocity, n);
+    return hipGetLastError();
+}
+
+// wave64 shuffle reduction -> LDS across the 4 waves -> one fp64 atomic per block
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(const T *a, const T *b, int64_t n, double *out) {
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)a[i] * (double)b[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+template <typename T>
+hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256));
+    hipLaunchKernelGGL(dot_kernel<T>, dim3(blocks), dim3(256), 0, s, a, b, n, out);
+    return hipGetLastError();
+}
+
+#define FWI_INSTANTIATE(T)                                                                          \
+    template hipError_t launch_inject<T>(T *, T *, const int64_t *, const int64_t *, const T *,    \
+                                         const T *, const T *, int, hipStream_t);                  \
+    template hipError_t launch_record<T>(const T *, const int64_t *, T *, T, int, hipStream_t);    \
+    template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
+    template hipError_t launch_finalize_gradient<T>(const T *, const T *, T *, double, int, int64_t, \
+                                                    hipStream_t);                                  \
+    template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);
+FWI_INSTANTIATE(float)
+FWI_INSTANTIATE(double)
+
+}  // namespace fwi

@@ -1,0 +1,200 @@
+"""Host-side engine: one context per GPU behind the C-ABI (include/fwi.h).
+
+No reference counterpart; entry-point names and argument
+meaning follow BASELINE.json's north_star: forward(model, src, rec),
+adjoint(residual), gradient().  NumPy is used only to own host buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+_COEF_ABS_SUM = {2: 4.0, 4: 16.0 / 3.0, 8: 2048.0 / 315.0}
+
+
+def cfl_dt(c_max, h, ndim, order):
+    """Stability limit of the leapfrog scheme, 2 h / (c_max sqrt(D sum|a_k|))."""
+    return 2.0 * h / (c_max * math.sqrt(ndim * _COEF_ABS_SUM[order]))
+
+
+def default_sigma_max(c_max, h, npml, refl=1e-3):
+    """Peak damping rate of the quadratic sponge for a target reflection coefficient."""
+    return 0.0 if npml <= 0 else 3.0 * c_max * math.log(1.0 / refl) / (2.0 * npml * h)
+
+
+def ricker(nt, dt, f0, t0=None, dtype=np.float32):
+    t0 = 1.5 / f0 if t0 is None else t0
+    a = (np.pi * f0 * (np.arange(nt) * dt - t0)) ** 2
+    return ((1.0 - 2.0 * a) * np.exp(-a)).astype(dtype)
+
+
+class Engine:
+    """Acoustic forward / adjoint / gradient on one MI355X.
+
+    ``shape`` is (nz, nx) or (nz, ny, nx); ``model`` arrays are velocities in
+    m/s of that shape.  Stateful like the C-ABI: ``adjoint`` uses the last
+    ``forward``; ``gradient`` returns the sum over all adjoint calls since
+    ``reset_gradient``.
+    """
+
+    def __init__(self, shape, h, dt, nt_max, order=8, npml=0, sigma_max=None, dtype="float32",
+                 device=0, kernel="auto", zchunk=0):
+        shape = tuple(int(s) for s in shape)
+        if len(shape) not in (2, 3):
+            raise ValueError("shape must be (nz, nx) or (nz, ny, nx)")
+        self.shape, self.ndim = shape, len(shape)
+        self.h, self.dt, self.order, self.npml = float(h), float(dt), int(order), int(npml)
+        self.nt_max = int(nt_max)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self.sigma_max = sigma_max
+        self.device = int(device)
+        self._kernel = {"auto": _lib.KERNEL_AUTO, "point": _lib.KERNEL_POINT,
+                        "stream": _lib.KERNEL_STREAM}[kernel]
+        self._zchunk = int(zchunk)
+        self._lib = _lib.load()
+        self._ctx = None
+        self._nsrc = self._nrec = self._nt = 0
+
+    # -- context ---------------------------------------------------------------
+    def _create(self, c_max):
+        if self.sigma_max is None:
+            self.sigma_max = default_sigma_max(c_max, self.h, self.npml)
+        nz, nx = self.shape[0], self.shape[-1]
+        ny = self.shape[1] if self.ndim == 3 else 1
+        cfg = _lib.Config(C.sizeof(_lib.Config), self.ndim, nz, ny, nx, self.order, self.nt_max,
+                          self.npml, self.device,
+                          _lib.F32 if self.dtype == np.float32 else _lib.F64, self._kernel,
+                          self._zchunk, self.h, self.dt, float(self.sigma_max))
+        ctx = C.c_void_p()
+        _lib.check(None, self._lib.fwi_create(C.byref(cfg), C.byref(ctx)))
+        self._ctx = ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.fwi_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, code):
+        _lib.check(self._ctx, code)
+
+    def _host(self, a, shape=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if shape is not None and a.shape != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), a.shape))
+        return a
+
+    def _idx(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int32).reshape(-1, self.ndim))
+        return idx
+
+    @property
+    def kernel_name(self):
+        return self._lib.fwi_kernel_name(self._ctx).decode() if self._ctx is not None else ""
+
+    # -- the three entry points ------------------------------------------------
+    def set_model(self, model):
+        model = self._host(model, self.shape)
+        if self._ctx is None:
+            self._create(float(model.max()))
+        self._chk(self._lib.fwi_set_model(self._ctx, model.ctypes.data_as(C.c_void_p)))
+
+    def forward(self, model, src, rec, save=True):
+        """Seismograms ``(nt, nrec)``.  ``src = (src_idx (nsrc, ndim), wavelet (nt[, nsrc]))``."""
+        if model is not None:
+            self.set_model(model)
+        if self._ctx is None:
+            raise _lib.FwiError(3, "forward: no model set")
+        src_idx, wavelet = src
+        src_idx = self._idx(src_idx)
+        rec_idx = self._idx(rec)
+        wavelet = np.asarray(wavelet)
+        if wavelet.ndim == 1:
+            wavelet = wavelet[:, None]
+        wavelet = self._host(wavelet)
+        nt = wavelet.shape[0]
+        if wavelet.shape[1] != len(src_idx):
+            raise ValueError("wavelet must be (nt, nsrc)")
+        seis = np.zeros((nt, len(rec_idx)), self.dtype)
+        self._chk(self._lib.fwi_forward(
+            self._ctx, nt, len(src_idx), src_idx.ctypes.data_as(C.c_void_p),
+            wavelet.ctypes.data_as(C.c_void_p), len(rec_idx), rec_idx.ctypes.data_as(C.c_void_p),
+            int(bool(save)), seis.ctypes.data_as(C.c_void_p)))
+        self._nt, self._nsrc, self._nrec = nt, len(src_idx), len(rec_idx)
+        return seis
+
+    def adjoint(self, residual, image=True):
+        """Back-propagate ``residual (nt, nrec)``; returns ``F^T residual`` as ``(nt, nsrc)``."""
+        if self._ctx is None:
+            raise _lib.FwiError(3, "adjoint: no forward run to adjoin")
+        residual = self._host(residual, (self._nt, self._nrec))
+        out = np.zeros((self._nt, self._nsrc), self.dtype)
+        self._chk(self._lib.fwi_adjoint(self._ctx, residual.ctypes.data_as(C.c_void_p),
+                                        int(bool(image)), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gradient(self, wrt="velocity"):
+        if self._ctx is None:
+            raise _lib.FwiError(3, "gradient: no model set")
+        g = np.zeros(self.shape, self.dtype)
+        w = {"velocity": _lib.WRT_VELOCITY, "slowness2": _lib.WRT_SLOWNESS2}[wrt]
+        self._chk(self._lib.fwi_gradient(self._ctx, w, g.ctypes.data_as(C.c_void_p)))
+        return g
+
+    def reset_gradient(self):
+        if self._ctx is not None:
+            self._chk(self._lib.fwi_gradient_reset(self._ctx))
+
+    # -- reductions, exchange, measurement --------------------------------------
+    def dot(self, a, b):
+        a, b = self._host(a).ravel(), self._host(b).ravel()
+        if a.size != b.size:
+            raise ValueError("dot: size mismatch")
+        out = C.c_double(0.0)
+        self._chk(self._lib.fwi_dot(self._ctx, a.ctypes.data_as(C.c_void_p),
+                                    b.ctypes.data_as(C.c_void_p), a.size, C.byref(out)))
+        return out.value
+
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(None, _lib.load().fwi_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.UNIQUE_ID_BYTES)
+        self._chk(self._lib.fwi_comm_init(self._ctx, rank, nranks, C.c_char_p(unique_id)))
+
+    def allreduce_gradient(self):
+        self._chk(self._lib.fwi_allreduce_gradient(self._ctx))
+
+    def allreduce_f64(self, vals):
+        arr = (C.c_double * len(vals))(*vals)
+        self._chk(self._lib.fwi_allreduce_f64(self._ctx, arr, len(vals)))
+        return list(arr)
+
+    def last_loop_ms(self):
+        ms = C.c_double(0.0)
+        self._chk(self._lib.fwi_last_loop_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        self._chk(self._lib.fwi_synchronize(self._ctx))

@@ -1,0 +1,142 @@
+/* fwi.h -- C ABI of the MI355X-native acoustic forward / adjoint / gradient engine.
+ *
+ * Drop-in boundary.  The reference (Kevin2599/full_waveform_inversion) has NO
+ * plugin / operator / FFI interface and no wave-propagation code
+ * (SURVEY.md s.0, s.8b): its only seams are plain Python functions called
+ * positionally -- forward_model(green_func_array, M)
+ * (full_waveform_inversion.py:253), compare_synth_to_real_waveforms(...)
+ * (:584) and perform_monte_carlo_sampled_waveform_inversion(...) (:786).
+ * The entry points below are therefore the ones BASELINE.json's north_star
+ * names -- forward(model, src, rec), adjoint(residual), gradient() -- bound
+ * from Python through ctypes (full_waveform_inversion_amd/_lib.py); each
+ * declaration says which north_star item / SURVEY.md s.8(a-1) row it serves
+ * and, where one exists, the nearest reference line.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch / numpy types.
+ *  - Every function returns 0 on success or an FWI_E* code; the message is
+ *    available from fwi_last_error().  The library never calls exit()
+ *    (the reference print+sys.exit()s, full_waveform_inversion.py:124-125).
+ *  - Host buffers are caller-owned, C-contiguous, x fastest: a model is
+ *    (nz, nx) or (nz, ny, nx); time series are (nt, n).  Their element type is
+ *    the context's dtype (float for FWI_F32, double for FWI_F64).
+ *  - The library owns all device memory inside the context.  One context per
+ *    GPU, used from one host thread at a time.  It is stateful: fwi_adjoint()
+ *    consumes what the last fwi_forward(save=1) stored, fwi_gradient()
+ *    returns what the adjoint calls since the last fwi_gradient_reset()
+ *    accumulated (the sum over this rank's shots).
+ *  - Grid indices are int32 triples/pairs (z[, y], x).
+ */
+#ifndef FWI_H
+#define FWI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWI_ABI_VERSION 1
+
+enum { FWI_F32 = 0, FWI_F64 = 1 };
+
+/* Stencil kernel selection (FWI_KERNEL_AUTO picks the fastest valid one). */
+enum {
+    FWI_KERNEL_AUTO = 0,
+    FWI_KERNEL_POINT = 1,  /* one thread per grid point, neighbours through L1/L2 */
+    FWI_KERNEL_STREAM = 2  /* 3-D: z-marching register queue + LDS-staged xy halo tile */
+};
+
+enum { FWI_WRT_VELOCITY = 0, FWI_WRT_SLOWNESS2 = 1 };
+
+enum {
+    FWI_OK = 0,
+    FWI_EINVAL = 1,   /* bad argument / configuration */
+    FWI_EHIP = 2,     /* a HIP runtime call failed */
+    FWI_ESTATE = 3,   /* call order violated (e.g. adjoint before forward) */
+    FWI_ENOMEM = 4,   /* device or host allocation failed */
+    FWI_ECOMM = 5     /* RCCL failure */
+};
+
+typedef struct fwi_ctx fwi_ctx;
+
+typedef struct fwi_config {
+    int32_t struct_size; /* = sizeof(fwi_config); ABI guard */
+    int32_t ndim;        /* 2 or 3 */
+    int32_t nz, ny, nx;  /* ny is ignored (treated as 1) when ndim == 2 */
+    int32_t order;       /* spatial order 2, 4 or 8 */
+    int32_t nt_max;      /* largest number of time steps a shot will use */
+    int32_t npml;        /* absorbing border width in cells; 0 = off */
+    int32_t device;      /* HIP device ordinal */
+    int32_t dtype;       /* FWI_F32 or FWI_F64 */
+    int32_t kernel;      /* FWI_KERNEL_* */
+    int32_t zchunk;      /* STREAM kernel: planes marched per workgroup; 0 = auto */
+    double h;            /* grid spacing (m) */
+    double dt;           /* time step (s) */
+    double sigma_max;    /* peak damping rate (1/s) of the sponge, >= 0 (used when npml > 0) */
+} fwi_config;
+
+/* Context life cycle.  [north_star: "thin ctypes C-ABI shim"; SURVEY s.8b] */
+int fwi_create(const fwi_config *cfg, fwi_ctx **out);
+void fwi_destroy(fwi_ctx *ctx);
+/* Last error text of ctx (or of the failed fwi_create when ctx == NULL). */
+const char *fwi_last_error(const fwi_ctx *ctx);
+int fwi_abi_version(void);
+
+/* Upload the velocity model c (m/s), model-shaped.  The `model` argument of
+ * north_star's forward(model, src, rec).  [SURVEY s.8(a-1) row forward] */
+int fwi_set_model(fwi_ctx *ctx, const void *c_host);
+
+/* forward(model, src, rec): nt leapfrog steps of the 2-D/3-D O(2|4|8) stencil
+ * with sponge update, injection of wavelet (nt, nsrc) at src_idx (nsrc, ndim)
+ * and sampling at rec_idx (nrec, ndim) into seis_out (nt, nrec).  save != 0
+ * keeps the per-step forward term the imaging condition needs.
+ * [SURVEY s.8(a-1) rows forward / stencil / PML / source / receiver; the
+ * structurally analogous reference slot is forward_model(),
+ * full_waveform_inversion.py:253-264: unknowns -> synthetic seismograms] */
+int fwi_forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx,
+                const void *wavelet, int32_t nrec, const int32_t *rec_idx, int32_t save,
+                void *seis_out);
+
+/* adjoint(residual): reverse-time propagation of residual (nt, nrec) injected
+ * at the receivers of the last forward.  image != 0 accumulates the zero-lag
+ * forward x adjoint correlation into the gradient accumulator.  adj_src_out,
+ * if not NULL, receives F^T residual as (nt, nsrc).
+ * [SURVEY s.8(a-1) rows adjoint / imaging condition] */
+int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src_out);
+
+/* gradient(): copy out the accumulated gradient, model-shaped, as dJ/dc
+ * (FWI_WRT_VELOCITY) or dJ/d(1/c^2) (FWI_WRT_SLOWNESS2).
+ * [SURVEY s.8(a-1) row gradient] */
+int fwi_gradient(fwi_ctx *ctx, int32_t wrt, void *g_out);
+int fwi_gradient_reset(fwi_ctx *ctx);
+
+/* Device-side reductions for the misfit and the optimiser's dot products:
+ * sum_i a[i]*b[i] over n host elements of the context dtype, wave-shuffle
+ * reduced on the GPU, fp64 accumulate.  [SURVEY s.8(a-1) row dot-products] */
+int fwi_dot(fwi_ctx *ctx, const void *a_host, const void *b_host, int64_t n, double *out);
+
+/* Shot-parallel exchange: one RCCL communicator per context, sum of the
+ * gradient accumulators over ranks (in place, on device).  The reference's
+ * only counterpart is the gather-by-concatenation of Monte Carlo samples,
+ * full_waveform_inversion.py:816-848.  [SURVEY s.8e] */
+#define FWI_UNIQUE_ID_BYTES 128
+int fwi_comm_unique_id(void *id_out /* FWI_UNIQUE_ID_BYTES */);
+int fwi_comm_init(fwi_ctx *ctx, int32_t rank, int32_t nranks, const void *id);
+int fwi_allreduce_gradient(fwi_ctx *ctx);
+/* In-place sum over ranks of n doubles (misfit values etc.). */
+int fwi_allreduce_f64(fwi_ctx *ctx, double *vals, int32_t n);
+
+/* Measurement hooks (bench.py): device time of the last time loop, from HIP
+ * events on the context's stream, and the synchronising fence. */
+int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out);
+int fwi_synchronize(fwi_ctx *ctx);
+/* Name of the stencil kernel the context dispatches to (static string). */
+const char *fwi_kernel_name(const fwi_ctx *ctx);
+/* Device count / name without creating a context (returns FWI_EHIP if none). */
+int fwi_device_count(int32_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWI_H */

@@ -1,0 +1,242 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+"Oracle" = this build's own NumPy / C restatement (oracle/): the reference has
+no wave-propagation path, so these tests say "vs the build's
+oracle", never "vs the reference".  Tolerances: fp64 kernels 1e-10 (same
+arithmetic, different summation order), fp32 kernels 1e-5 relative L2 on
+seismograms, adjoint traces and gradient -- the figure BASELINE.json states.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import Engine, FwiError, workloads
+from oracle import fwi_oracle as fo
+from oracle.c_oracle import CPropagator
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL32 = 1e-5   # BASELINE.json north_star: "within 1e-5 relative L2"
+TOL64 = 1e-10
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
+                 np.linalg.norm(np.asarray(b, np.float64)))
+
+
+def run_gpu(c, h, dt, order, npml, sigma_max, src, w, rec, residual=None, dtype="float32",
+            kernel="auto", zchunk=0):
+    nt = w.shape[0]
+    with Engine(c.shape, h, dt, nt, order=order, npml=npml, sigma_max=sigma_max, dtype=dtype,
+                kernel=kernel, zchunk=zchunk) as e:
+        d = e.forward(c, (src, w), rec, save=residual is not None)
+        out = {"seis": d, "kernel": e.kernel_name}
+        if residual is not None:
+            out["adj_src"] = e.adjoint(residual)
+            out["grad_c"] = e.gradient("velocity")
+            out["grad_m"] = e.gradient("slowness2")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# committed golden fixtures (inputs + oracle outputs travel to the GPU box)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g2d_o8", "g2d_o2", "g3d_o8", "g3d_o4"])
+@pytest.mark.parametrize("dtype,kernel,tol", [("float64", "point", TOL64), ("float32", "point", TOL32),
+                                              ("float32", "auto", TOL32)])
+def test_golden(gpu, name, dtype, kernel, tol):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o = run_gpu(z["c"], float(z["h"]), float(z["dt"]), int(z["order"]), int(z["npml"]),
+                float(z["sigma_max"]), z["src_idx"], z["wavelet"], z["rec_idx"], z["residual"],
+                dtype=dtype, kernel=kernel)
+    assert rel(o["seis"], z["seis"]) < tol
+    assert rel(o["adj_src"], z["adj_src"]) < tol
+    assert rel(o["grad_c"], z["grad_c"]) < 3 * tol
+    assert rel(o["grad_m"], z["grad_m"]) < 3 * tol
+
+
+# ---------------------------------------------------------------------------
+# seeded random cases against the oracle run on the spot, incl. ragged shapes
+# ---------------------------------------------------------------------------
+SHAPES = [
+    ((33, 47), 8, 6), ((64, 64), 2, 0), ((50, 30), 4, 5),          # 2-D
+    ((20, 17, 23), 8, 4), ((16, 16, 64), 8, 0), ((12, 40, 36), 2, 3),  # 3-D, ragged / nx%4 != 0
+    ((24, 24, 260), 8, 5),                                          # more than one 256-wide x tile
+    ((9, 8, 8), 8, 0),                                              # grid barely wider than the stencil
+]
+
+
+@pytest.mark.parametrize("shape,order,npml", SHAPES)
+@pytest.mark.parametrize("dtype,tol", [("float64", TOL64), ("float32", TOL32)])
+def test_random_model_vs_oracle(gpu, shape, order, npml, dtype, tol):
+    rng = np.random.default_rng(hash((shape, order)) % 2 ** 32)
+    nd = len(shape)
+    c = 1500.0 + 1500.0 * rng.random(shape)
+    h = 7.5
+    dt = 0.7 * fo.cfl_dt(c.max(), h, nd, order)
+    nt = 70
+    src = np.stack([rng.integers(0, s, 3) for s in shape], 1)
+    src[2] = src[1]  # two sources on the same node: amplitudes add
+    rec = np.stack([rng.integers(0, s, 11) for s in shape], 1)
+    rec[0] = src[0]
+    w = rng.standard_normal((nt, 3)) * fo.ricker(nt, dt, 20.0)[:, None]
+    p = CPropagator(c, h, dt, order, npml)
+    d = p.forward(src, w, rec)
+    r = d + 0.1 * np.abs(d).max() * rng.standard_normal(d.shape)
+    a = p.adjoint(r)
+    o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r, dtype=dtype)
+    assert rel(o["seis"], d) < tol
+    assert rel(o["adj_src"], a) < tol
+    assert rel(o["grad_c"], p.gradient()) < 3 * tol
+
+
+@pytest.mark.parametrize("zchunk", [0, 5, 16, 1000])
+def test_stream_kernel_matches_point_kernel(gpu, zchunk):
+    """Same inputs through both stencil kernels (and several z-chunkings)."""
+    w = workloads.cfg4(0.25, npml=6)  # 64^3
+    wav = w.wavelet()
+    a = run_gpu(w.c, w.h, w.dt, w.order, w.npml, None, w.src_idx, wav, w.rec_idx, kernel="point")
+    b = run_gpu(w.c, w.h, w.dt, w.order, w.npml, None, w.src_idx, wav, w.rec_idx, kernel="stream",
+                zchunk=zchunk)
+    assert a["kernel"] == "step_point" and b["kernel"] == "step3d_stream"
+    assert rel(b["seis"], a["seis"]) < 2e-6
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's configs, scaled so the oracle finishes in seconds
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("maker,scale", [(workloads.cfg1, 1.0), (workloads.cfg2, 0.25),
+                                         (workloads.cfg4, 0.375), (workloads.cfg5, 0.25)])
+def test_baseline_configs_scaled(gpu, maker, scale):
+    w = maker(scale)
+    wav = w.wavelet(np.float64)
+    src = w.src_idx[:1]
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    d = p.forward(src, wav, w.rec_idx)
+    c0 = w.c_init if w.c_init is not None else w.c * 1.02
+    p0 = CPropagator(c0, w.h, w.dt, w.order, w.npml, sigma_max=p.sigma_max)
+    d0 = p0.forward(src, wav, w.rec_idx)
+    p0.adjoint(d0 - d)
+    nt = w.nt
+    with Engine(w.shape, w.h, w.dt, nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max) as e:
+        dg = e.forward(w.c, (src, wav), w.rec_idx, save=False)
+        assert rel(dg, d) < TOL32
+        dg0 = e.forward(c0, (src, wav), w.rec_idx, save=True)
+        assert rel(dg0, d0) < TOL32
+        e.adjoint((d0 - d).astype(np.float32))   # same residual for both paths
+        assert rel(e.gradient(), p0.gradient()) < TOL32
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties at (or near) BASELINE.json's full sizes
+# ---------------------------------------------------------------------------
+def test_full_size_3d_adjoint_identity_and_linearity(gpu):
+    """256^3 O(8), 300 steps: <F s, r> = <s, F^T r> and F(2s) = 2 F(s), no oracle needed."""
+    w = workloads.cfg4(1.0, npml=16)
+    nt = 300
+    rng = np.random.default_rng(0)
+    wav = w.wavelet()[:nt]
+    with Engine(w.shape, w.h, w.dt, nt, order=8, npml=16) as e:
+        assert e.kernel_name == "step3d_stream"
+        d = e.forward(w.c.astype(np.float32), (w.src_idx, wav), w.rec_idx, save=False)
+        d2 = e.forward(None, (w.src_idx, 2 * wav), w.rec_idx, save=False)
+        assert rel(d2, 2 * d) < 1e-6
+        r = (rng.standard_normal(d.shape) * np.abs(d).max()).astype(np.float32)
+        a = e.adjoint(r, image=False)
+        lhs = e.dot(d, r)
+        rhs = e.dot(wav[:, None], a)
+        assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs))
+
+
+def test_full_size_2d_vs_c_oracle(gpu):
+    """cfg2 at full 1024^2 grid, 400 steps: the C oracle still finishes in seconds."""
+    w = workloads.cfg2(1.0)
+    nt = 400
+    wav = w.wavelet(np.float64)[:nt]
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    d = p.forward(w.src_idx, wav, w.rec_idx, save=False)
+    o = run_gpu(w.c, w.h, w.dt, w.order, w.npml, p.sigma_max, w.src_idx, wav, w.rec_idx)
+    assert rel(o["seis"], d) < TOL32
+
+
+# ---------------------------------------------------------------------------
+# edge cases and error behaviour
+# ---------------------------------------------------------------------------
+def test_empty_point_sets(gpu):
+    c = np.full((16, 16, 16), 2000.0, np.float32)
+    with Engine(c.shape, 10.0, 1e-3, 8) as e:
+        d = e.forward(c, (np.zeros((0, 3), np.int32), np.zeros((8, 0), np.float32)), [[3, 3, 3]])
+        assert d.shape == (8, 1) and not d.any()
+        d = e.forward(None, ([[8, 8, 8]], np.ones(8, np.float32)), np.zeros((0, 3), np.int32))
+        assert d.shape == (8, 0)
+
+
+def test_gradient_accumulates_over_shots_and_resets(gpu):
+    w = workloads.cfg2(0.125, nshots=3)
+    wav = w.wavelet()
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) as e:
+        e.set_model(w.c.astype(np.float32))
+        gs = []
+        for s in range(3):
+            e.reset_gradient()
+            d = e.forward(None, (w.src_idx[s:s + 1], wav), w.rec_idx)
+            e.adjoint(d)
+            gs.append(e.gradient())
+        e.reset_gradient()
+        for s in range(3):
+            d = e.forward(None, (w.src_idx[s:s + 1], wav), w.rec_idx)
+            e.adjoint(d)
+        assert rel(e.gradient(), gs[0] + gs[1] + gs[2]) < 1e-5
+        e.reset_gradient()
+        assert not e.gradient().any()
+
+
+def test_error_paths(gpu):
+    c = np.full((16, 16), 2000.0, np.float32)
+    with Engine(c.shape, 10.0, 1e-3, 8) as e:
+        with pytest.raises(FwiError) as ei:
+            e.adjoint(np.zeros((0, 0), np.float32))
+        assert ei.value.code == 3  # FWI_ESTATE: nothing to adjoin
+        with pytest.raises(FwiError) as ei:
+            e.forward(c, ([[16, 0]], np.ones(8, np.float32)), [[1, 1]])
+        assert ei.value.code == 1 and "outside the grid" in str(ei.value)
+        with pytest.raises(FwiError) as ei:
+            e.forward(c, ([[1, 1]], np.ones(9, np.float32)), [[1, 1]])
+        assert ei.value.code == 1  # nt > nt_max
+        e.forward(c, ([[8, 8]], np.ones(8, np.float32)), [[1, 1]], save=False)
+        with pytest.raises(FwiError) as ei:
+            e.adjoint(np.zeros((8, 1), np.float32), image=True)
+        assert ei.value.code == 3  # imaging needs save=True
+        with pytest.raises(FwiError):
+            e.set_model(np.zeros_like(c))  # velocity must be > 0
+    with pytest.raises(FwiError):
+        Engine((8, 8, 8), 10.0, 1e-3, 4, dtype="float64", kernel="stream").set_model(
+            np.full((8, 8, 8), 2000.0))
+
+
+def test_dot_product_reduction(gpu):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(1_000_003).astype(np.float32)
+    b = rng.standard_normal(1_000_003).astype(np.float32)
+    with Engine((8, 8), 10.0, 1e-3, 2) as e:
+        e.set_model(np.full((8, 8), 2000.0, np.float32))
+        got = e.dot(a, b)
+    ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    assert abs(got - ref) < 1e-9 * np.sqrt(a.size) * 10 + 1e-12 * abs(ref)
+
+
+def test_single_rank_rccl_allreduce(gpu):
+    """RCCL communicator of one rank: all-reduce must leave the gradient unchanged."""
+    w = workloads.cfg2(0.125)
+    wav = w.wavelet()
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) as e:
+        d = e.forward(w.c.astype(np.float32), (w.src_idx, wav), w.rec_idx)
+        e.adjoint(d)
+        g0 = e.gradient()
+        e.comm_init(0, 1, Engine.comm_unique_id())
+        e.allreduce_gradient()
+        assert np.array_equal(e.gradient(), g0)
+        assert e.allreduce_f64([1.5, -2.0]) == [1.5, -2.0]

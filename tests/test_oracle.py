@@ -1,0 +1,188 @@
+"""Validation ladder of the CPU oracle (oracle/), which is BUILD-DEFINED.
+
+PARITY UNPINNED: the reference has no wave-propagation / adjoint / gradient
+code, hence no golden vectors to pin the oracle with.  What
+pins it instead: analytic point-source solutions, the exact adjoint identity,
+finite-difference gradient checks, stability at the CFL limit, and frozen
+fixtures of its own output (tests/golden/, made by tests/golden/make_golden.py)
+so that later edits cannot silently change the definition.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fwi_oracle as fo
+from oracle.c_oracle import CPropagator
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _random_case(shape, order, nt=40, npml=5, seed=0, nsrc=2, nrec=6):
+    rng = np.random.default_rng(seed)
+    c = 1500.0 + 1000.0 * rng.random(shape)
+    h = 10.0
+    dt = 0.6 * fo.cfl_dt(c.max(), h, len(shape), order)
+    src = np.stack([rng.integers(0, s, nsrc) for s in shape], 1)
+    rec = np.stack([rng.integers(0, s, nrec) for s in shape], 1)
+    w = rng.standard_normal((nt, nsrc))
+    r = rng.standard_normal((nt, nrec))
+    return c, h, dt, src, rec, w, r
+
+
+CASES = [((30, 26), 2), ((30, 26), 4), ((30, 26), 8), ((14, 12, 16), 2), ((14, 12, 16), 8)]
+
+
+@pytest.mark.parametrize("shape,order", CASES)
+def test_adjoint_identity(shape, order):
+    """<F s, r> = <s, F^T r> to round-off: the adjoint is the exact transpose."""
+    c, h, dt, src, rec, w, r = _random_case(shape, order)
+    p = fo.Propagator(c, h, dt, order, npml=5)
+    d = p.forward(src, w, rec)
+    a = p.adjoint(r, image=False)
+    lhs, rhs = np.sum(d * r), np.sum(w * a)
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs))
+
+
+@pytest.mark.parametrize("shape,order", [((30, 26), 8), ((30, 26), 2), ((14, 12, 16), 8)])
+@pytest.mark.parametrize("wrt", ["velocity", "slowness2"])
+def test_gradient_matches_finite_differences(shape, order, wrt):
+    c, h, dt, src, rec, w, _ = _random_case(shape, order, seed=3)
+    p0 = fo.Propagator(c, h, dt, order, npml=5)
+    d_obs = p0.forward(src, w, rec, save=False)
+    rng = np.random.default_rng(7)
+    c1 = c * (1.0 + 0.02 * rng.standard_normal(shape))
+    dc = rng.standard_normal(shape)
+    sm = p0.sigma_max
+
+    def J(cc):
+        return fo.misfit_and_gradient(cc, h, dt, order, 5, src, w, rec, d_obs, sigma_max=sm, wrt=wrt)
+
+    _, g, _ = J(c1)
+    eps = 1e-3
+    if wrt == "velocity":
+        fd = (J(c1 + eps * dc)[0] - J(c1 - eps * dc)[0]) / (2 * eps)
+    else:  # perturb m = 1/c^2
+        m1 = 1.0 / c1 ** 2
+        dm = dc * 1e-9
+        fd = (J((m1 + eps * dm) ** -0.5)[0] - J((m1 - eps * dm) ** -0.5)[0]) / (2 * eps)
+        dc = dm
+    an = np.sum(g * dc)
+    assert abs(fd - an) <= 1e-6 * abs(fd)
+
+
+def test_analytic_3d_point_source():
+    """Homogeneous 3-D: u(r, t) = w(t - r/c) / (4 pi r) for (1/c^2) u_tt - lap u = w delta."""
+    n, h, c0, f0 = 72, 10.0, 2000.0, 12.0
+    dt = 0.4 * fo.cfl_dt(c0, h, 3, 8)
+    nt = 190
+    w = fo.ricker(nt, dt, f0)
+    src = [[n // 2] * 3]
+    offs = np.array([12, 18, 24])
+    rec = np.stack([np.full(3, n // 2), np.full(3, n // 2), n // 2 + offs], 1)
+    p = fo.Propagator(np.full((n, n, n), c0), h, dt, 8, npml=0)
+    d = p.forward(src, w, rec, save=False)
+    t = (np.arange(nt) + 1) * dt  # d[n] samples u^{n+1}
+    for i, o in enumerate(offs):
+        r = o * h
+        ex = np.interp(t - r / c0, np.arange(nt) * dt, w, left=0.0) / (4 * np.pi * r)
+        assert rel(d[:, i], ex) < 0.03
+
+
+def test_analytic_2d_point_source():
+    """Homogeneous 2-D: u = (1/2pi) int w(tau) H(t-tau-r/c) / sqrt((t-tau)^2 - r^2/c^2) dtau."""
+    n, h, c0, f0 = 220, 10.0, 2000.0, 10.0
+    dt = 0.4 * fo.cfl_dt(c0, h, 2, 8)
+    nt = 360
+    w = fo.ricker(nt, dt, f0)
+    src = [[n // 2, n // 2]]
+    off = 40
+    rec = [[n // 2, n // 2 + off]]
+    p = fo.Propagator(np.full((n, n), c0), h, dt, 8, npml=0)
+    d = p.forward(src, w, rec, save=False)[:, 0]
+    r = off * h
+    t = (np.arange(nt) + 1) * dt
+    # substitution t - tau = (r/c) cosh(s) removes the inverse-square-root singularity
+    s = np.linspace(0.0, 6.0, 4001)
+    ex = np.zeros(nt)
+    tw = np.arange(nt) * dt
+    for k, tk in enumerate(t):
+        tau = tk - (r / c0) * np.cosh(s)
+        ex[k] = np.trapezoid(np.interp(tau, tw, w, left=0.0, right=0.0), s) / (2 * np.pi)
+    assert rel(d, ex) < 0.03
+
+
+def test_cfl_limit():
+    """Stable just below the CFL bound of cfl_dt(), unstable above it."""
+    n = 40
+    c = np.full((n, n), 2000.0)
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((300, 1))
+    for fac, stable in [(0.99, True), (1.05, False)]:
+        dt = fac * fo.cfl_dt(2000.0, 10.0, 2, 8)
+        p = fo.Propagator(c, 10.0, dt, 8, npml=0)
+        with np.errstate(over="ignore", invalid="ignore"):
+            d = p.forward([[n // 2, n // 2]], w, [[3, 3]], save=False)
+        big = not np.all(np.isfinite(d)) or np.abs(d).max() > 1e6 * np.abs(d[:50]).max()
+        assert big != stable
+
+
+def test_sponge_absorbs():
+    """With the absorbing border the late-time energy at a receiver is far below the undamped run."""
+    n = 90
+    c = np.full((n, n), 2000.0)
+    dt = 0.7 * fo.cfl_dt(2000.0, 10.0, 2, 8)
+    nt = 700
+    w = fo.ricker(nt, dt, 15.0)
+    late = slice(450, nt)
+    e = []
+    for npml in (0, 20):
+        p = fo.Propagator(c, 10.0, dt, 8, npml=npml)
+        d = p.forward([[n // 2, n // 2]], w, [[n // 2, n // 2 + 10]], save=False)
+        e.append(np.sum(d[late] ** 2))
+    assert e[1] < 1e-3 * e[0]
+
+
+@pytest.mark.parametrize("shape,order", CASES)
+def test_c_oracle_matches_numpy_oracle(shape, order):
+    c, h, dt, src, rec, w, r = _random_case(shape, order, seed=5)
+    p, q = fo.Propagator(c, h, dt, order, 5), CPropagator(c, h, dt, order, 5)
+    assert rel(q.forward(src, w, rec), p.forward(src, w, rec)) < 1e-13
+    assert rel(q.q_store, p.q_store) < 1e-13
+    assert rel(q.adjoint(r), p.adjoint(r)) < 1e-13
+    assert rel(q.gradient(), p.gradient()) < 1e-12
+
+
+def test_empty_point_sets():
+    """No sources -> zero data; no receivers -> (nt, 0) output; both oracles agree."""
+    c = np.full((20, 20), 2000.0)
+    dt = 0.5 * fo.cfl_dt(2000.0, 10.0, 2, 8)
+    for P in (fo.Propagator, CPropagator):
+        p = P(c, 10.0, dt, 8, 4)
+        d = p.forward(np.zeros((0, 2), int), np.zeros((10, 0)), [[5, 5]])
+        assert d.shape == (10, 1) and not d.any()
+        d = p.forward([[5, 5]], np.ones((10, 1)), np.zeros((0, 2), int))
+        assert d.shape == (10, 0)
+
+
+def test_index_outside_grid_is_rejected():
+    p = fo.Propagator(np.full((10, 10), 2000.0), 10.0, 1e-3, 2)
+    with pytest.raises(ValueError):
+        p.forward([[10, 0]], np.ones((4, 1)), [[1, 1]])
+
+
+@pytest.mark.parametrize("name", ["g2d_o8", "g2d_o2", "g3d_o8", "g3d_o4"])
+def test_golden_fixtures(name):
+    """The oracle still reproduces its own frozen outputs (definition drift guard)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    p = fo.Propagator(z["c"], float(z["h"]), float(z["dt"]), int(z["order"]), int(z["npml"]),
+                      sigma_max=float(z["sigma_max"]))
+    d = p.forward(z["src_idx"], z["wavelet"], z["rec_idx"])
+    assert rel(d, z["seis"]) < 1e-12
+    a = p.adjoint(z["residual"])
+    assert rel(a, z["adj_src"]) < 1e-12
+    assert rel(p.gradient(), z["grad_c"]) < 1e-11
