@@ -28,8 +28,9 @@ BYTES_PER_UPDATE = 16        # read u_cur, u_prev, C; write u_ne
 def cpu_baseline(w, sample_steps):
     """The oracle's OpenMP C port (fp64) on the same grid for the first `sample_steps` steps."""
     from oracle.c_oracle import CPropagator
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    from oracle.c_oracle import default_threads
+    cores = int(os.environ.get("OMP_NUM_THREADS", default_threads()))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
     wav = w.wavelet(np.float64)[:sample_steps]
     p.forward(w.src_idx, wav[:2], w.rec_idx, save=False)  # warm-up / page-in

@@ -60,6 +60,8 @@ class Engine:
         self._lib = _lib.load()
         self._ctx = None
         self._nsrc = self._nrec = self._nt = 0
+        if self.npml == 0 or self.sigma_max is not None:
+            self._create(0.0)  # damping does not depend on the model: create the context now
 
     # -- context ---------------------------------------------------------------
     def _create(self, c_max):

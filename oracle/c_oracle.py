@@ -26,9 +26,23 @@ def build(force=False):
     return _SO
 
 
+def default_threads():
+    """Threads for the OpenMP loops: the CPUs this process may use, at most 16.
+
+    The GPU boxes expose every host core but give a job a 16-CPU share; an
+    uncapped OpenMP team oversubscribes that share and crawls.
+    """
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))
         _lib = ctypes.CDLL(build())
         f = _lib.fwi_oracle_propagate
         f.restype = ctypes.c_int

@@ -63,7 +63,10 @@ def test_create_rejects_bad_configs_before_touching_the_gpu():
 def test_no_device_means_loud_failure_not_fallback():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible; covered by the gpu tests")
-    e = Engine((8, 8, 8), 10.0, 1e-3, 4)
+    with pytest.raises(FwiError) as ei:  # npml = 0: the context is created eagerly
+        Engine((8, 8, 8), 10.0, 1e-3, 4)
+    assert ei.value.code == 2 and "no CPU fallback" in str(ei.value)
+    e = Engine((8, 8, 8), 10.0, 1e-3, 4, npml=2)  # damping needs c_max: created at set_model
     with pytest.raises(FwiError) as ei:
         e.forward(np.full((8, 8, 8), 2000.0, np.float32), ([[4, 4, 4]], np.ones(4, np.float32)), [[1, 1, 1]])
     assert ei.value.code == 2 and "no CPU fallback" in str(ei.value)

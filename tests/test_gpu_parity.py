@@ -115,7 +115,7 @@ def test_baseline_configs_scaled(gpu, maker, scale):
     wav = w.wavelet(np.float64)
     src = w.src_idx[:1]
     p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
-    d = p.forward(src, wav, w.rec_idx)
+    d = p.forward(src, wav, w.rec_idx, save=False)
     c0 = w.c_init if w.c_init is not None else w.c * 1.02
     p0 = CPropagator(c0, w.h, w.dt, w.order, w.npml, sigma_max=p.sigma_max)
     d0 = p0.forward(src, wav, w.rec_idx)
@@ -140,8 +140,8 @@ def test_full_size_3d_adjoint_identity_and_linearity(gpu):
     rng = np.random.default_rng(0)
     wav = w.wavelet()[:nt]
     with Engine(w.shape, w.h, w.dt, nt, order=8, npml=16) as e:
-        assert e.kernel_name == "step3d_stream"
         d = e.forward(w.c.astype(np.float32), (w.src_idx, wav), w.rec_idx, save=False)
+        assert e.kernel_name == "step3d_stream"
         d2 = e.forward(None, (w.src_idx, 2 * wav), w.rec_idx, save=False)
         assert rel(d2, 2 * d) < 1e-6
         r = (rng.standard_normal(d.shape) * np.abs(d).max()).astype(np.float32)

@@ -47,7 +47,7 @@ def main():
             d = e.forward(None, (w.src_idx, wav), w.rec_idx, save=False)
             if ref is None:
                 ref = d
-            err = float(np.linalg.norm(d - ref) / np.linalg.norm(ref))
+            err = float(np.linalg.norm(d - ref) / max(np.linalg.norm(ref), 1e-30))
             if r:
                 res[v].append(e.last_loop_ms())
             if err > 1e-5:
