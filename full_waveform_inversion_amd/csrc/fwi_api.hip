@@ -478,7 +478,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
         if (const char *ty = getenv("FWI_STREAM_TY")) {  // tuning hook: rows per workgroup
             const int v = atoi(ty);
-            if (v == 4 || v == 8 || v == 16) ctx->tune.ty = v;
+            if (v == 4 || v == 8) ctx->tune.ty = v;
         }
     }
     int rc = create_impl(ctx);

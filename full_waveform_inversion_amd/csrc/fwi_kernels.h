@@ -43,7 +43,7 @@ struct StepArgs {
 enum StencilKernel { K_POINT = 1, K_STREAM = 2 };
 
 struct StreamTuning {
-    int ty;      // rows per workgroup (4, 8 or 16)
+    int ty;      // rows per workgroup (4 or 8)
     int zchunk;  // planes marched per workgroup
 };
 

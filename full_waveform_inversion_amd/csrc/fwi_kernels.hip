@@ -108,11 +108,12 @@ __device__ __forceinline__ void st4(float *p, const f4 &v) { *reinterpret_cast<f
 constexpr int TILE_X = 256;                // floats per tile row = 64 lanes x float4
 constexpr int LROW4 = TILE_X / 4 + 2;      // LDS row in float4: [left edge][64][right edge]
 
-template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE>
+template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE, bool FULL>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk) {
-    constexpr int LROWS = TY + 2 * R;
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
+    constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
+    constexpr int LROWS = TY + 2 * R + 1;
     __shared__ f4 lds[2][LROWS][LROW4];
 
     const int lane = threadIdx.x, ty = threadIdx.y;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     const int y0 = by * TY, y = y0 + ty;
     const int z0 = bz * zchunk;
     const int z1 = min(g.nz, z0 + zchunk);
-    const bool act = (x0 < g.nx) && (y < g.ny);
+    const bool act = FULL || ((x0 < g.nx) && (y < g.ny));
     const int64_t sz = g.sz, sy = g.sy;
     const int zlast = g.nz + HALO - 1;  // last padded plane (interior-relative)
 
@@ -136,16 +137,27 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     const unsigned coff = (unsigned)((int64_t)y * g.nx + x0);         // compact, z = 0
     const int64_t cplane = (int64_t)g.ny * g.nx;
 
-    // halo rows this thread fetches: hr in [0, 2R), below (hr < R) or above the tile
+    // The loop below is free of divergent branches so that hipcc can count its
+    // s_waitcnt vmcnt(N) exactly and keep the prefetches in flight across
+    // iterations: slots with nothing to fetch re-load their own address and
+    // write to the TRASH row instead of branching.
+    // Halo rows: hr in [0, 2R), below (hr < R) or above the tile.
     unsigned hoff[NH];
     int hrow[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
         const int hr = ty + i * TY;
-        const int yh = (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
-        hrow[i] = (hr < 2 * R) ? ((hr < R) ? hr : TY + hr) : -1;
+        const bool valid = hr < 2 * R;
+        const int yh = !valid ? y : (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
+        hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
         hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + x0);
     }
+    // x edges: lanes 0-3 fetch the 4 floats left of the tile row, lanes 60-63
+    // the 4 floats right of it (one dword each).
+    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TILE_X);
+    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
+    const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : 4 + 4 * lane;
 
     // loop-invariant xy part of the damping
     f4 Axy, Bxy, dxy;
@@ -160,105 +172,108 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
         }
     }
 
-    // z register queue: zq[k] = plane z - R + k
-    f4 zq[2 * R + 1];
+    // z register queue of NQ = 2R+2 slots: plane p lives in slot (p - z0 + R) % NQ, one slot
+    // more than the stencil needs so the next plane is fetched straight into the queue.
+    // The z loop is unrolled NQ times: every queue / double-buffer index below is a
+    // compile-time constant, so there are no register rotations and hipcc can keep the
+    // prefetches of plane z+1 in flight while plane z is computed (exact vmcnt counts).
+    constexpr int NQ = 2 * R + 2;
+    f4 zq[NQ];
 #pragma unroll
-    for (int k = 0; k < 2 * R; ++k) zq[k + 1] = ld4(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
-    f4 zfront = ld4(a.u_cur + (int64_t)(z0 + R) * sz + poff);
-    f4 up = ld4(a.u_prev + (int64_t)z0 * sz + poff), Cc = ld4(a.C + (int64_t)z0 * sz + poff);
-    f4 halo[NH], edge;
+    for (int k = 0; k <= 2 * R; ++k) zq[k] = ld4(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
+    f4 up[2], Cc[2], halo[2][NH];
+    float edge[2];
+    up[0] = ld4(a.u_prev + (int64_t)z0 * sz + poff);
+    Cc[0] = ld4(a.C + (int64_t)z0 * sz + poff);
 #pragma unroll
-    for (int i = 0; i < NH; ++i)
-        if (hrow[i] >= 0) halo[i] = ld4(a.u_cur + (int64_t)z0 * sz + hoff[i]);
-    // lanes 0 / 63 also carry the 16 B to the left / right of the tile row
-    const bool is_edge = (lane == 0) || (lane == 63);
-    const unsigned eoff = (lane == 0) ? poff - 4 : poff + 4;
-    const int ecol = (lane == 0) ? 0 : LROW4 - 1;
-    if (is_edge) edge = ld4(a.u_cur + (int64_t)z0 * sz + eoff);
+    for (int i = 0; i < NH; ++i) halo[0][i] = ld4(a.u_cur + (int64_t)z0 * sz + hoff[i]);
+    edge[0] = a.u_cur[(int64_t)z0 * sz + eoff];
 
-    for (int z = z0; z < z1; ++z) {
+    for (int zb = z0; zb < z1; zb += NQ) {
 #pragma unroll
-        for (int k = 0; k < 2 * R; ++k) zq[k] = zq[k + 1];
-        zq[2 * R] = zfront;
+        for (int ph = 0; ph < NQ; ++ph) {
+            const int z = zb + ph;
+            if (z >= z1) break;
+            const int cur = ph & 1, nxt = cur ^ 1;  // NQ is even: parity is static
+            // slot of plane z - R + k is (ph + k) % NQ
+            const f4 &ctr = zq[(ph + R) % NQ];
 
-        // stage the plane's rows in LDS (double buffered: one barrier per plane)
-        f4(*L)[LROW4] = lds[z & 1];
-        L[R + ty][1 + lane] = zq[R];
+            // stage the plane's rows in LDS (double buffered: one barrier per plane)
+            f4(*L)[LROW4] = lds[z & 1];
+            L[R + ty][1 + lane] = ctr;
 #pragma unroll
-        for (int i = 0; i < NH; ++i)
-            if (hrow[i] >= 0) L[hrow[i]][1 + lane] = halo[i];
-        if (is_edge) L[R + ty][ecol] = edge;
+            for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[cur][i];
+            reinterpret_cast<float *>(&L[erow][0])[ecol] = edge[cur];
 
-        // refill the consumed registers one plane ahead
-        zfront = ld4(a.u_cur + (int64_t)min(z + R + 1, zlast) * sz + poff);
-        const float *ucn = a.u_cur + (int64_t)min(z + 1, zlast) * sz;
+            // fetch plane z+1's operands (and plane z+R+1 of the queue) while z is computed
+            const int64_t on = (int64_t)min(z + 1, zlast) * sz;
+            zq[(ph + 2 * R + 1) % NQ] = ld4(a.u_cur + (int64_t)min(z + R + 1, zlast) * sz + poff);
 #pragma unroll
-        for (int i = 0; i < NH; ++i)
-            if (hrow[i] >= 0) halo[i] = ld4(ucn + hoff[i]);
-        if (is_edge) edge = ld4(ucn + eoff);
-        f4 qi, gi;
-        if (IMAGE && act) {
-            qi = ld4(a.q_in + (int64_t)z * cplane + coff);
-            gi = ld4(a.g + (int64_t)z * cplane + coff);
-        }
-        __syncthreads();
+            for (int i = 0; i < NH; ++i) halo[nxt][i] = ld4(a.u_cur + on + hoff[i]);
+            edge[nxt] = a.u_cur[on + eoff];
+            up[nxt] = ld4(a.u_prev + on + poff);
+            Cc[nxt] = ld4(a.C + on + poff);
+            f4 qi, gi;
+            if (IMAGE) {
+                const unsigned co = act ? coff : 0u;
+                qi = ld4(a.q_in + (int64_t)z * cplane + co);
+                gi = ld4(a.g + (int64_t)z * cplane + co);
+            }
+            __syncthreads();
 
-        const f4 xl = L[R + ty][lane], xr = L[R + ty][lane + 2];
-        float X[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            X[j] = xl.v[j];
-            X[4 + j] = zq[R].v[j];
-            X[8 + j] = xr.v[j];
-        }
-        f4 lap;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lap.v[j] = 0.f;
-#pragma unroll
-        for (int k = R; k >= 1; --k) {
-            const f4 ym = L[R + ty - k][1 + lane], yp = L[R + ty + k][1 + lane];
-            const f4 zm = zq[R - k], zp = zq[R + k];
-            const float c = a.ck[k];
+            const f4 xl = L[R + ty][lane], xr = L[R + ty][lane + 2];
+            float X[12];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float t = (X[4 + j - k] + X[4 + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
-                t = fmaf(-6.f, X[4 + j], t);
-                lap.v[j] = fmaf(c, t, lap.v[j]);
+                X[j] = xl.v[j];
+                X[4 + j] = ctr.v[j];
+                X[8 + j] = xr.v[j];
             }
-        }
-
-        f4 A = Axy, B = Bxy;
-        if (DAMP) {
-            const float dzv = a.dz[z];
-            if (dzv != 0.f) {
+            f4 lap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lap.v[j] = 0.f;
+#pragma unroll
+            for (int k = R; k >= 1; --k) {
+                const f4 ym = L[R + ty - k][1 + lane], yp = L[R + ty + k][1 + lane];
+                const f4 &zm = zq[(ph + R - k) % NQ], &zp = zq[(ph + R + k) % NQ];
+                const float c = a.ck[k];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d = dxy.v[j] + dzv;
-                    B.v[j] = 1.f - d;
-                    A.v[j] = 1.f / (1.f + d);
+                    float t = (X[4 + j - k] + X[4 + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
+                    t = fmaf(-6.f, X[4 + j], t);
+                    lap.v[j] = fmaf(c, t, lap.v[j]);
                 }
             }
-        }
-        f4 q, un;
+
+            f4 A = Axy, B = Bxy;
+            if (DAMP) {
+                const float dzv = a.dz[z];
+                if (dzv != 0.f) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            q.v[j] = Cc.v[j] * lap.v[j];
-            if (DAMP)
-                un.v[j] = (fmaf(2.f, X[4 + j], -B.v[j] * up.v[j]) + q.v[j]) * A.v[j];
-            else
-                un.v[j] = (2.f * X[4 + j] - up.v[j]) + q.v[j];
-        }
-        // next plane's pointwise operands go into the registers just consumed
-        const int64_t on = (int64_t)min(z + 1, zlast) * sz;
-        up = ld4(a.u_prev + on + poff);
-        Cc = ld4(a.C + on + poff);
-        if (act) {
-            st4(a.u_prev + (int64_t)z * sz + poff, un);
-            if (SAVE_Q) st4(a.q_out + (int64_t)z * cplane + coff, q);
-            if (IMAGE) {
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = dxy.v[j] + dzv;
+                        B.v[j] = 1.f - d;
+                        A.v[j] = 1.f / (1.f + d);
+                    }
+                }
+            }
+            f4 q, un;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
-                st4(a.g + (int64_t)z * cplane + coff, gi);
+            for (int j = 0; j < 4; ++j) {
+                q.v[j] = Cc[cur].v[j] * lap.v[j];
+                if (DAMP)
+                    un.v[j] = (fmaf(2.f, X[4 + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
+                else
+                    un.v[j] = (2.f * X[4 + j] - up[cur].v[j]) + q.v[j];
+            }
+            if (act) {
+                st4(a.u_prev + (int64_t)z * sz + poff, un);
+                if (SAVE_Q) st4(a.q_out + (int64_t)z * cplane + coff, q);
+                if (IMAGE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+                    st4(a.g + (int64_t)z * cplane + coff, gi);
+                }
             }
         }
     }
@@ -280,8 +295,8 @@ StreamTuning stream_default_tuning(const GridDesc &g) {
     return t;
 }
 
-template <int R, int TY, bool DAMP>
-static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk,
+template <int R, int TY, bool DAMP, bool FULL>
+static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a, int zchunk,
                                      hipStream_t s) {
     const int nxt = (int)(round_up(g.nx, TILE_X) / TILE_X);
     const int nyt = (g.ny + TY - 1) / TY;
@@ -289,15 +304,23 @@ static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a
     const int nblk = nxt * nyt * nzc;
     dim3 block(64, TY), grid(nblk);
     if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false>), grid, block, 0, s, a, g, zchunk,
-                           nxt, nyt, nblk);
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL>), grid, block, 0, s, a, g,
+                           zchunk, nxt, nyt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true>), grid, block, 0, s, a, g, zchunk,
-                           nxt, nyt, nblk);
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true, FULL>), grid, block, 0, s, a, g,
+                           zchunk, nxt, nyt, nblk);
     else
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false, FULL>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     return hipGetLastError();
+}
+
+template <int R, int TY, bool DAMP>
+static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk,
+                                     hipStream_t s) {
+    // FULL: every thread of every tile owns grid points, so the stores need no predicate
+    if (g.nx % TILE_X == 0 && g.ny % TY == 0) return launch_stream_full<R, TY, DAMP, true>(g, a, zchunk, s);
+    return launch_stream_full<R, TY, DAMP, false>(g, a, zchunk, s);
 }
 
 template <int R>
@@ -307,13 +330,11 @@ static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, c
     if (a.damp) {
         switch (t.ty) {
             case 4: return launch_stream_mode<R, 4, true>(g, a, zc, s);
-            case 16: return launch_stream_mode<R, 16, true>(g, a, zc, s);
             default: return launch_stream_mode<R, 8, true>(g, a, zc, s);
         }
     }
     switch (t.ty) {
         case 4: return launch_stream_mode<R, 4, false>(g, a, zc, s);
-        case 16: return launch_stream_mode<R, 16, false>(g, a, zc, s);
         default: return launch_stream_mode<R, 8, false>(g, a, zc, s);
     }
 }

@@ -139,10 +139,12 @@ def test_full_size_3d_adjoint_identity_and_linearity(gpu):
     nt = 300
     rng = np.random.default_rng(0)
     wav = w.wavelet()[:nt]
+    src = np.array([[40, 128, 128]])  # 32 cells below the receiver patch: arrivals by step ~170
     with Engine(w.shape, w.h, w.dt, nt, order=8, npml=16) as e:
-        d = e.forward(w.c.astype(np.float32), (w.src_idx, wav), w.rec_idx, save=False)
+        d = e.forward(w.c.astype(np.float32), (src, wav), w.rec_idx, save=False)
         assert e.kernel_name == "step3d_stream"
-        d2 = e.forward(None, (w.src_idx, 2 * wav), w.rec_idx, save=False)
+        assert np.abs(d).max() > 1e-12
+        d2 = e.forward(None, (src, 2 * wav), w.rec_idx, save=False)
         assert rel(d2, 2 * d) < 1e-6
         r = (rng.standard_normal(d.shape) * np.abs(d).max()).astype(np.float32)
         a = e.adjoint(r, image=False)

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--nt", type=int, default=200)
     ap.add_argument("--npml", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--ty", default="4,8,16")
+    ap.add_argument("--ty", default="4,8")
     ap.add_argument("--zchunk", default="16,32,64,128,256")
     ap.add_argument("--point", type=int, default=1)
     a = ap.parse_args()
