@@ -65,10 +65,17 @@ struct fwi_ctx {
     // per-shot point sets (device) and their sizes
     int nt = 0, nsrc = 0, nrec = 0;
     bool have_forward = false, have_q = false;
-    void *src_p = nullptr, *src_c = nullptr, *rec_p = nullptr, *rec_c = nullptr;  // int64 idx
-    void *src_cu = nullptr, *src_cq = nullptr, *rec_cu = nullptr, *rec_cq = nullptr;  // coefs
+    // A point set on the device: original order (sampling, POINT-kernel injection) and the
+    // copy sorted by stream-kernel tile with its CSR offsets (fused injection).
+    struct PointSet {
+        int n = 0;
+        void *pidx = nullptr, *cidx = nullptr, *cu = nullptr, *cq = nullptr;
+        void *s_start = nullptr, *s_pidx = nullptr, *s_cidx = nullptr, *s_cu = nullptr, *s_cq = nullptr,
+             *s_col = nullptr;
+        size_t cap = 0, cap_start = 0;
+    } src, rec;
     void *amp = nullptr, *series = nullptr;  // (nt, ninj) injected / (nt, nrec) recorded
-    size_t cap_pts = 0, cap_amp = 0, cap_series = 0;
+    size_t cap_amp = 0, cap_series = 0;
 
     ncclComm_t comm = nullptr;
     int nranks = 1;
@@ -160,6 +167,14 @@ struct Impl {
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
         for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / (ctx->cfg.h * ctx->cfg.h));
         a.damp = ctx->cfg.npml > 0;
+        a.inj_start = nullptr;
+        a.inj_pidx = a.inj_cidx = nullptr;
+        a.inj_cu = a.inj_cq = a.inj_amp = nullptr;
+        a.inj_col = nullptr;
+        a.rec_pidx = nullptr;
+        a.rec_out = nullptr;
+        a.rec_scale = T(0);
+        a.nrec = 0;
         return a;
     }
 
@@ -208,46 +223,80 @@ struct Impl {
         }
     }
 
-    static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
-                             const int32_t *rec_idx) {
+    static int upload_set(fwi_ctx *ctx, fwi_ctx::PointSet &ps, int32_t n, const int32_t *idx,
+                          double scale) {
         const GridDesc &g = ctx->gd;
-        std::vector<int64_t> sp, sc, rp, rc;
+        std::vector<int64_t> p, c;
         int rcode;
-        if ((rcode = flatten(ctx, src_idx, nsrc, sp, sc))) return rcode;
-        if ((rcode = flatten(ctx, rec_idx, nrec, rp, rc))) return rcode;
-        std::vector<T> scu, scq, rcu, rcq;
-        point_coefs(ctx, src_idx, nsrc, 1.0 / std::pow(ctx->cfg.h, g.ndim), scu, scq);
-        point_coefs(ctx, rec_idx, nrec, 1.0, rcu, rcq);
-        const size_t need = (size_t)std::max(nsrc, nrec) * 8 + 16;
-        if (ctx->cap_pts < need) {
-            void **ps[] = {&ctx->src_p, &ctx->src_c, &ctx->rec_p, &ctx->rec_c,
-                           &ctx->src_cu, &ctx->src_cq, &ctx->rec_cu, &ctx->rec_cq};
-            for (void **p : ps) {
-                if (*p) HIPCHK(ctx, hipFree(*p));
-                *p = nullptr;
-                HIPCHK(ctx, hipMalloc(p, need));
+        if ((rcode = flatten(ctx, idx, n, p, c))) return rcode;
+        std::vector<T> cu, cq;
+        point_coefs(ctx, idx, n, scale, cu, cq);
+        const size_t need = (size_t)n * 8 + 16;
+        if (ps.cap < need) {
+            for (void **q : {&ps.pidx, &ps.cidx, &ps.cu, &ps.cq, &ps.s_pidx, &ps.s_cidx, &ps.s_cu, &ps.s_cq,
+                             &ps.s_col}) {
+                if (*q) HIPCHK(ctx, hipFree(*q));
+                *q = nullptr;
+                HIPCHK(ctx, hipMalloc(q, need));
             }
-            ctx->cap_pts = need;
+            ps.cap = need;
         }
         auto up = [&](void *d, const void *h, size_t b) {
             return b ? hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
         };
-        HIPCHK(ctx, up(ctx->src_p, sp.data(), (size_t)nsrc * 8));
-        HIPCHK(ctx, up(ctx->src_c, sc.data(), (size_t)nsrc * 8));
-        HIPCHK(ctx, up(ctx->rec_p, rp.data(), (size_t)nrec * 8));
-        HIPCHK(ctx, up(ctx->rec_c, rc.data(), (size_t)nrec * 8));
-        HIPCHK(ctx, up(ctx->src_cu, scu.data(), (size_t)nsrc * sizeof(T)));
-        HIPCHK(ctx, up(ctx->src_cq, scq.data(), (size_t)nsrc * sizeof(T)));
-        HIPCHK(ctx, up(ctx->rec_cu, rcu.data(), (size_t)nrec * sizeof(T)));
-        HIPCHK(ctx, up(ctx->rec_cq, rcq.data(), (size_t)nrec * sizeof(T)));
+        HIPCHK(ctx, up(ps.pidx, p.data(), (size_t)n * 8));
+        HIPCHK(ctx, up(ps.cidx, c.data(), (size_t)n * 8));
+        HIPCHK(ctx, up(ps.cu, cu.data(), (size_t)n * sizeof(T)));
+        HIPCHK(ctx, up(ps.cq, cq.data(), (size_t)n * sizeof(T)));
+        std::vector<int> start, col;
+        std::vector<int64_t> sp, sc;
+        std::vector<T> scu, scq;
+        if (ctx->kernel == K_STREAM) {  // counting sort of the entries by workgroup tile
+            const int ntile = stream_num_tiles(g, ctx->tune);
+            start.assign(ntile + 1, 0);
+            std::vector<int> tile(n);
+            for (int i = 0; i < n; ++i) {
+                const int32_t *t = idx + (size_t)i * g.ndim;
+                tile[i] = stream_tile_of(g, ctx->tune, t[0], t[1], t[2]);
+                ++start[tile[i] + 1];
+            }
+            for (int k = 0; k < ntile; ++k) start[k + 1] += start[k];
+            std::vector<int> fill(start.begin(), start.end() - 1);
+            col.resize(n); sp.resize(n); sc.resize(n); scu.resize(n); scq.resize(n);
+            for (int i = 0; i < n; ++i) {
+                const int k = fill[tile[i]]++;
+                col[k] = i; sp[k] = p[i]; sc[k] = c[i]; scu[k] = cu[i]; scq[k] = cq[i];
+            }
+            const size_t sb = start.size() * sizeof(int);
+            if (ps.cap_start < sb) {
+                if (ps.s_start) HIPCHK(ctx, hipFree(ps.s_start));
+                ps.s_start = nullptr;
+                HIPCHK(ctx, hipMalloc(&ps.s_start, sb));
+                ps.cap_start = sb;
+            }
+            HIPCHK(ctx, up(ps.s_start, start.data(), sb));
+            HIPCHK(ctx, up(ps.s_pidx, sp.data(), (size_t)n * 8));
+            HIPCHK(ctx, up(ps.s_cidx, sc.data(), (size_t)n * 8));
+            HIPCHK(ctx, up(ps.s_cu, scu.data(), (size_t)n * sizeof(T)));
+            HIPCHK(ctx, up(ps.s_cq, scq.data(), (size_t)n * sizeof(T)));
+            HIPCHK(ctx, up(ps.s_col, col.data(), (size_t)n * sizeof(int)));
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+        ps.n = n;
         return FWI_OK;
     }
 
-    // The shared time loop (oracle: Propagator._propagate).
-    static int propagate(fwi_ctx *ctx, bool reverse, int ninj, const void *inj_p, const void *inj_c,
-                         const void *inj_cu, const void *inj_cq, int nrecd, const void *rec_p,
-                         T rec_scale, bool save_q, bool image) {
+    static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
+                             const int32_t *rec_idx) {
+        int rc = upload_set(ctx, ctx->src, nsrc, src_idx, 1.0 / std::pow(ctx->cfg.h, ctx->gd.ndim));
+        if (rc) return rc;
+        return upload_set(ctx, ctx->rec, nrec, rec_idx, 1.0);
+    }
+
+    // The shared time loop (oracle: Propagator._propagate): inject `amp` rows at point set
+    // `inj`, sample the new field at point set `out` into `series`.
+    static int propagate(fwi_ctx *ctx, bool reverse, const fwi_ctx::PointSet &inj,
+                         const fwi_ctx::PointSet &out, T out_scale, bool save_q, bool image) {
         const GridDesc &g = ctx->gd;
         const int nt = ctx->nt;
         hipStream_t s = ctx->stream;
@@ -256,7 +305,11 @@ struct Impl {
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         const T *amp = (const T *)ctx->amp;
-        int cur = 0;
+        // STREAM kernel: injection and sampling are fused into the step launch (sampling of
+        // step n rides on launch n+1, which reads that field anyway); POINT kernel: separate
+        // small launches.
+        const bool fused = ctx->kernel == K_STREAM;
+        int cur = 0, prev_n = -1;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         for (int it = 0; it < nt; ++it) {
             const int n = reverse ? nt - 1 - it : it;
@@ -264,14 +317,37 @@ struct Impl {
             if (save_q) a.q_out = q_store + (size_t)n * g.npts;
             // lagged imaging: u_cur of adjoint step n is mu^{n+2}, which pairs with q^{n+1}
             if (image && n + 1 < nt) a.q_in = q_store + (size_t)(n + 1) * g.npts;
+            if (fused) {
+                if (inj.n > 0) {
+                    a.inj_start = (const int *)inj.s_start;
+                    a.inj_pidx = (const int64_t *)inj.s_pidx;
+                    a.inj_cidx = (const int64_t *)inj.s_cidx;
+                    a.inj_cu = (const T *)inj.s_cu;
+                    a.inj_cq = (const T *)inj.s_cq;
+                    a.inj_col = (const int *)inj.s_col;
+                    a.inj_amp = amp + (size_t)n * inj.n;
+                }
+                if (prev_n >= 0 && out.n > 0) {
+                    a.rec_pidx = (const int64_t *)out.pidx;
+                    a.rec_out = series + (size_t)prev_n * out.n;
+                    a.rec_scale = out_scale;
+                    a.nrec = out.n;
+                }
+            }
             HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, s));
-            HIPCHK(ctx, launch_inject<T>((T *)ctx->u[cur ^ 1], a.q_out, (const int64_t *)inj_p,
-                                         (const int64_t *)inj_c, (const T *)inj_cu, (const T *)inj_cq,
-                                         amp + (size_t)n * ninj, ninj, s));
-            HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur ^ 1], (const int64_t *)rec_p,
-                                         series + (size_t)n * nrecd, rec_scale, nrecd, s));
+            if (!fused) {
+                HIPCHK(ctx, launch_inject<T>((T *)ctx->u[cur ^ 1], a.q_out, (const int64_t *)inj.pidx,
+                                             (const int64_t *)inj.cidx, (const T *)inj.cu,
+                                             (const T *)inj.cq, amp + (size_t)n * inj.n, inj.n, s));
+                HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur ^ 1], (const int64_t *)out.pidx,
+                                             series + (size_t)n * out.n, out_scale, out.n, s));
+            }
+            prev_n = n;
             cur ^= 1;
         }
+        if (fused)  // the last step's field has no following launch to ride on
+            HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur], (const int64_t *)out.pidx,
+                                         series + (size_t)prev_n * out.n, out_scale, out.n, s));
         if (image)  // the last pairing: mu^1 with q^0
             HIPCHK(ctx, launch_image<T>(g, (const T *)ctx->u[cur], q_store, (T *)ctx->g_acc, s));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
@@ -309,8 +385,7 @@ struct Impl {
         if (nsrc)
             HIPCHK(ctx, hipMemcpyAsync(ctx->amp, wavelet, (size_t)nt * nsrc * sizeof(T),
                                        hipMemcpyHostToDevice, ctx->stream));
-        rc = propagate(ctx, false, nsrc, ctx->src_p, ctx->src_c, ctx->src_cu, ctx->src_cq, nrec,
-                       ctx->rec_p, T(1), save != 0, false);
+        rc = propagate(ctx, false, ctx->src, ctx->rec, T(1), save != 0, false);
         if (rc) return rc;
         if (nrec && seis_out)
             HIPCHK(ctx, hipMemcpyAsync(seis_out, ctx->series, (size_t)nt * nrec * sizeof(T),
@@ -327,8 +402,7 @@ struct Impl {
             HIPCHK(ctx, hipMemcpyAsync(ctx->amp, residual, (size_t)ctx->nt * ctx->nrec * sizeof(T),
                                        hipMemcpyHostToDevice, ctx->stream));
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
-        int rc = propagate(ctx, true, ctx->nrec, ctx->rec_p, ctx->rec_c, ctx->rec_cu, ctx->rec_cq,
-                           ctx->nsrc, ctx->src_p, rs, false, image != 0);
+        int rc = propagate(ctx, true, ctx->rec, ctx->src, rs, false, image != 0);
         if (rc) return rc;
         if (adj_src_out && ctx->nsrc)
             HIPCHK(ctx, hipMemcpyAsync(adj_src_out, ctx->series, (size_t)ctx->nt * ctx->nsrc * sizeof(T),
@@ -497,8 +571,11 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
-                    ctx->g_acc, ctx->g_out, ctx->red, ctx->src_p, ctx->src_c, ctx->rec_p, ctx->rec_c,
-                    ctx->src_cu, ctx->src_cq, ctx->rec_cu, ctx->rec_cq, ctx->amp, ctx->series};
+                    ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series};
+    for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
+        for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
+                        ps->s_cq, ps->s_col})
+            if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

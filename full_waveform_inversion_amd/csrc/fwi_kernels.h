@@ -38,6 +38,20 @@ struct StepArgs {
     T *g;            // compact gradient accumulator (used with q_in)
     T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
     int damp;        // npml > 0
+
+    // Point operations fused into the stream kernel (all nullptr / 0 = none).
+    // Injection into u_next (and q_out): entries sorted by workgroup tile,
+    // inj_start[tile] .. inj_start[tile + 1] is the tile's slice.
+    const int *inj_start;
+    const int64_t *inj_pidx, *inj_cidx;  // padded / compact flat index per entry
+    const T *inj_cu, *inj_cq;            // coefficient of the amplitude in u / in q
+    const int *inj_col;                  // column of the entry in the amplitude row
+    const T *inj_amp;                    // amplitude row of this time step
+    // Sampling of u_cur (= the previous step's result) by extra workgroups.
+    const int64_t *rec_pidx;
+    T *rec_out;
+    T rec_scale;
+    int nrec;
 };
 
 enum StencilKernel { K_POINT = 1, K_STREAM = 2 };
@@ -46,6 +60,11 @@ struct StreamTuning {
     int ty;      // rows per workgroup (4 or 8)
     int zchunk;  // planes marched per workgroup
 };
+
+// Workgroup tile of the stream kernel that owns grid point (z, y, x): the index
+// into StepArgs::inj_start.  Must match the kernel's block decode.
+int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x);
+int stream_num_tiles(const GridDesc &g, const StreamTuning &t);
 
 // True when the stream kernel supports this grid / dtype.
 bool stream_supported(const GridDesc &g, bool is_f32);

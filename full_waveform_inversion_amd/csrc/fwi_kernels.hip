@@ -118,6 +118,13 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
 
     const int lane = threadIdx.x, ty = threadIdx.y;
     int bid = blockIdx.x;
+    if (bid >= nblk) {
+        // Receiver sampling rides along as extra workgroups: u_cur is read-only in this
+        // launch and already holds the previous step's field including its injection.
+        for (int i = (bid - nblk) * (64 * TY) + ty * 64 + lane; i < a.nrec; i += (gridDim.x - nblk) * 64 * TY)
+            a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
+        return;
+    }
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous slabs
     const int bx = bid % nxt;
     const int t2 = bid / nxt;
@@ -277,6 +284,32 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             }
         }
     }
+
+    // Source / residual injection into the points this workgroup has just written.
+    // Wave-uniform and almost always empty; the barrier (which drains this workgroup's
+    // stores, vmcnt(0)) orders the float atomics after the plain stores of u_next.
+    if (a.inj_start) {
+        const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
+        if (s1 > s0) {
+            __syncthreads();
+            for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
+                const float amp = a.inj_amp[a.inj_col[i]];
+                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
+                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
+            }
+        }
+    }
+}
+
+static inline int stream_nxt(const GridDesc &g) { return (int)(round_up(g.nx, TILE_X) / TILE_X); }
+
+int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x) {
+    const int nxt = stream_nxt(g), nyt = (g.ny + t.ty - 1) / t.ty;
+    return ((z / t.zchunk) * nyt + y / t.ty) * nxt + x / TILE_X;
+}
+
+int stream_num_tiles(const GridDesc &g, const StreamTuning &t) {
+    return stream_nxt(g) * ((g.ny + t.ty - 1) / t.ty) * ((g.nz + t.zchunk - 1) / t.zchunk);
 }
 
 bool stream_supported(const GridDesc &g, bool is_f32) {
@@ -284,15 +317,20 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g) {
-    StreamTuning t;
-    t.ty = 8;
-    // One 512-thread workgroup per CU measured fastest on MI355X (256^3: zchunk 32 -> 337 Gpts/s,
-    // 16 -> 306, 64 -> 207): enough workgroups for the 256 CUs, z halo re-read (zc+8)/zc kept small.
-    const int64_t tiles_xy = round_up(g.nx, TILE_X) / TILE_X * (round_up(g.ny, t.ty) / t.ty);
-    int zc = g.nz;
-    while (zc > 16 && tiles_xy * ((g.nz + zc - 1) / zc) < 256) zc = (zc + 1) / 2;
-    t.zchunk = zc;
-    return t;
+    // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
+    // (about one per CU, 256 CUs) each marching as many planes as possible, because every
+    // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
+    // (256 workgroups) 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256 328 vs TY 4 x 256 302
+    // (8 rows per tile halve the y-halo re-read once the z chunks are long anyway).
+    StreamTuning best{4, g.nz};
+    for (int ty : {8, 4}) {
+        const int64_t tiles_xy = stream_nxt(g) * (round_up(g.ny, ty) / ty);
+        const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
+        const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
+        best = StreamTuning{ty, zc};
+        if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
+    }
+    return best;
 }
 
 template <int R, int TY, bool DAMP, bool FULL>
@@ -302,7 +340,8 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a
     const int nyt = (g.ny + TY - 1) / TY;
     const int nzc = (g.nz + zchunk - 1) / zchunk;
     const int nblk = nxt * nyt * nzc;
-    dim3 block(64, TY), grid(nblk);
+    const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
+    dim3 block(64, TY), grid(nblk + nrb);
     if (a.q_out)
         hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
