@@ -32,6 +32,7 @@ def cpu_baseline(w, sample_steps):
     cores = int(os.environ.get("OMP_NUM_THREADS", default_threads()))
     os.environ["OMP_NUM_THREADS"] = str(cores)
     p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    sample_steps = min(sample_steps, w.nt)
     wav = w.wavelet(np.float64)[:sample_steps]
     p.forward(w.src_idx, wav[:2], w.rec_idx, save=False)  # warm-up / page-in
     t0 = time.perf_counter()
@@ -44,6 +45,23 @@ def cpu_baseline(w, sample_steps):
                                                                     sample_steps, w.nt, el)}
 
 
+def measured_traffic(kernel_name, shape):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
+
+    PMC counters cannot be collected inside this process; the numbers come from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, condensed by
+    tools/summarize_profile.py.  Only quoted when kernel and grid match what is being run.
+    """
+    path = os.path.join(ROOT, "profiles", "r01_step3d_stream_%d.json" % shape[0])
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if kernel_name not in prof.get("kernel", "") or len(set(shape)) != 1:
+        return None, None
+    return prof["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +72,8 @@ def main():
     ap.add_argument("--npml", type=int, default=0)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--zchunk", type=int, default=0)
-    ap.add_argument("--cpu-steps", type=int, default=60, help="time steps of the CPU baseline sample; 0 = skip")
+    ap.add_argument("--cpu-steps", type=int, default=1000,
+                    help="time steps of the CPU baseline sample (1000 = the whole shot, ~12 s on 16 cores); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +134,7 @@ def main():
         value = world * args.steps * updates / el / 1e9
         kern_us = 1e3 * float(np.mean(loop_ms)) / w.nt  # avg launch-to-launch time of the step kernel
         achieved = BYTES_PER_UPDATE * npts / (kern_us * 1e-6) / 1e9
+        traffic, traffic_src = measured_traffic(e.kernel_name, w.shape)
         out = {
             "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic",
             "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
@@ -126,7 +146,9 @@ def main():
                        "kernel": e.kernel_name, "parallelism": "shot-parallel x%d" % world,
                        "exchange": "rccl allreduce of the gradient accumulator per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * npts,
                          "kernel_avg_us": round(kern_us, 2),
                          "note": "algorithmic 16 B/update x %d updates per launch / HIP-event time of the "
                                  "%d-launch loop; working set 3 x %d MiB" % (npts, w.nt, npts * 4 >> 20)},

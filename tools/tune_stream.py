@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--ty", default="4,8")
     ap.add_argument("--zchunk", default="16,32,64,128,256")
     ap.add_argument("--point", type=int, default=1)
+    ap.add_argument("--mode", default="forward", choices=["forward", "save", "adjoint"],
+                    help="forward: plain steps; save: forward storing the imaging term; "
+                         "adjoint: reverse-time steps with the imaging condition")
     a = ap.parse_args()
     w = workloads.cfg4(a.grid / 256.0, npml=a.npml)
     w.nt = a.nt
@@ -44,22 +47,27 @@ def main():
     ref = None
     for r in range(a.rounds + 1):
         for v, e in zip(variants, engines):
-            d = e.forward(None, (w.src_idx, wav), w.rec_idx, save=False)
+            d = e.forward(None, (w.src_idx, wav), w.rec_idx, save=a.mode != "forward")
+            ms = e.last_loop_ms()
+            if a.mode == "adjoint":
+                e.adjoint(np.ones_like(d) * 1e-3)
+                ms = e.last_loop_ms()
             if ref is None:
                 ref = d
             err = float(np.linalg.norm(d - ref) / max(np.linalg.norm(ref), 1e-30))
             if r:
-                res[v].append(e.last_loop_ms())
+                res[v].append(ms)
             if err > 1e-5:
                 print("MISMATCH", v, err)
     npts = int(np.prod(w.shape))
-    print("grid %d^3 nt %d npml %d" % (a.grid, a.nt, a.npml))
+    bpp = {"forward": 16, "save": 20, "adjoint": 28}[a.mode]  # SURVEY.md s.8d algorithmic bytes/update
+    print("grid %d^3 nt %d npml %d mode %s (%d B/update)" % (a.grid, a.nt, a.npml, a.mode, bpp))
     print("%-8s %3s %6s %10s %10s %8s %8s" % ("kernel", "ty", "zchunk", "us/step", "Gpts/s", "GB/s", "frac8T"))
     for v in variants:
         ms = float(np.median(res[v]))
         us = 1e3 * ms / a.nt
         g = npts / us / 1e3
-        print("%-8s %3d %6d %10.2f %10.1f %8.0f %8.3f" % (v[0], v[1], v[2], us, g, 16 * g, 16 * g / 8000))
+        print("%-8s %3d %6d %10.2f %10.1f %8.0f %8.3f" % (v[0], v[1], v[2], us, g, bpp * g, bpp * g / 8000))
 
 
 if __name__ == "__main__":
