@@ -167,6 +167,9 @@ struct Impl {
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
         for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / (ctx->cfg.h * ctx->cfg.h));
         a.damp = ctx->cfg.npml > 0;
+        a.npml = ctx->cfg.npml;
+        a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
+                                  ((double)ctx->cfg.npml * ctx->cfg.npml)) : T(0);
         a.inj_start = nullptr;
         a.inj_pidx = a.inj_cidx = nullptr;
         a.inj_cu = a.inj_cq = a.inj_amp = nullptr;

@@ -38,6 +38,8 @@ struct StepArgs {
     T *g;            // compact gradient accumulator (used with q_in)
     T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
     int damp;        // npml > 0
+    int npml;        // border width; with dz_scale lets the stream kernel form dz[z] without a load
+    T dz_scale;      // sigma_max dt / (2 npml^2): d_z(z) = dz_scale * dist(z)^2
 
     // Point operations fused into the stream kernel (all nullptr / 0 = none).
     // Injection into u_next (and q_out): entries sorted by workgroup tile,

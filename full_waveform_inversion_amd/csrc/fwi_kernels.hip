@@ -277,8 +277,12 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
 
             f4 A = Axy, B = Bxy;
             if (DAMP) {
-                const float dzv = a.dz[z];
-                if (dzv != 0.f) {
+                // d_z(z) from the plane index: a load here would be a VECTOR load (the compiler
+                // cannot prove the profile is not aliased by the u_next stores) whose wait
+                // drains every prefetch in flight
+                const int dist = max(0, max(a.npml - z, z - (g.nz - 1 - a.npml)));
+                if (dist != 0) {
+                    const float dzv = a.dz_scale * (float)(dist * dist);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float d = dxy.v[j] + dzv;
