@@ -242,3 +242,43 @@ def test_single_rank_rccl_allreduce(gpu):
         e.allreduce_gradient()
         assert np.array_equal(e.gradient(), g0)
         assert e.allreduce_f64([1.5, -2.0]) == [1.5, -2.0]
+
+
+# ---------------------------------------------------------------------------
+# shot loop + optimiser on the real engine (BASELINE configs[2] / [4], scaled)
+# ---------------------------------------------------------------------------
+def test_shot_loop_gradient_vs_oracle(gpu):
+    """cfg3 scaled: 4 shots, summed misfit and gradient at the smoothed start model."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_engine import OracleEngine
+    from full_waveform_inversion_amd import shots as sh
+
+    w = workloads.cfg3(0.125, nshots=4)  # 128 x 128, 250 steps
+    res = []
+    for make, dt in ((lambda **k: OracleEngine(w.shape, w.h, w.dt, w.nt, **k), np.float64),
+                     (lambda **k: Engine(w.shape, w.h, w.dt, w.nt, **k), np.float32)):
+        wav = w.wavelet(dt)
+        shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
+        e = make(order=w.order, npml=w.npml, sigma_max=res[0][2] if res else None)
+        sh.model_data(e, w.c, shots)
+        J, g = sh.misfit_and_gradient(e, w.c_init, shots)
+        res.append((J, g, e.sigma_max))
+    assert abs(res[1][0] - res[0][0]) < 1e-5 * res[0][0]
+    assert rel(res[1][1], res[0][1]) < TOL32
+
+
+def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
+    """cfg5 scaled (3-D, smooth random model): 3 L-BFGS iterations with the GPU dot product."""
+    from full_waveform_inversion_amd import shots as sh
+    from full_waveform_inversion_amd.lbfgs import lbfgs
+
+    w = workloads.cfg5(0.1875, nshots=4)  # 48^3
+    wav = w.wavelet()
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) as e:
+        sh.model_data(e, w.c.astype(np.float32), shots)
+        fg = lambda m: sh.misfit_and_gradient(e, m, shots)  # noqa: E731
+        _, _, log = lbfgs(fg, w.c_init.astype(np.float32), maxiter=3, history=3, first_step=40.0,
+                          bounds=(1000.0, 5000.0), dot=e.dot)
+    assert log[-1]["f"] < 0.6 * log[0]["f"], log

@@ -1,0 +1,115 @@
+"""Host-side logic on CPU: workloads, shot sharding, exchange over gloo (world_size 2), L-BFGS."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import shots as sh, workloads
+from full_waveform_inversion_amd.lbfgs import lbfgs
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _oracle_engine import OracleEngine  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_covers_every_shot_once():
+    for n in (0, 1, 5, 32, 64):
+        for world in (1, 2, 3, 8):
+            parts = [sh.partition_shots(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    with pytest.raises(ValueError):
+        sh.partition_shots(4, 2, 2)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_workloads_are_deterministic_and_stable(name):
+    a, b = workloads.CONFIGS[name](0.125), workloads.CONFIGS[name](0.125)
+    assert np.array_equal(a.c, b.c) and a.dt == b.dt and np.array_equal(a.rec_idx, b.rec_idx)
+    from full_waveform_inversion_amd import cfl_dt
+    assert a.dt < cfl_dt(a.c.max(), a.h, a.ndim, a.order)
+    for idx in (a.src_idx, a.rec_idx):
+        assert idx.min() >= 0 and all(idx[:, k].max() < a.shape[k] for k in range(a.ndim))
+
+
+def test_full_size_configs_match_baseline_json():
+    assert workloads.cfg1().shape == (256, 256) and workloads.cfg1().nt == 500 and workloads.cfg1().order == 2
+    w2 = workloads.cfg2()
+    assert w2.shape == (1024, 1024) and w2.nt == 2000 and w2.order == 8 and w2.npml > 0
+    assert len(workloads.cfg3().src_idx) == 32
+    w4 = workloads.cfg4()
+    assert w4.shape == (256, 256, 256) and w4.nt == 1000 and w4.order == 8
+
+
+def _serial_reference():
+    w = workloads.cfg3(0.0625, nshots=5)
+    wav = w.wavelet(np.float64)
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(len(w.src_idx))]
+    e = OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml)
+    sh.model_data(e, w.c, shots)
+    return sh.misfit_and_gradient(e, w.c_init, shots)
+
+
+def test_shot_parallel_gloo_world2_matches_serial(tmp_path):
+    """Two processes, 5 shots split 3 + 2, gradient and misfit summed over gloo == serial."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o.decode()[-2000:]
+    J, g = _serial_reference()
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    assert list(res[0]["mine"]) == [0, 2, 4] and list(res[1]["mine"]) == [1, 3]
+    for r in res:  # every rank holds the full sum
+        assert abs(float(r["J"]) - J) <= 1e-12 * J
+        assert np.linalg.norm(r["g"] - g) <= 1e-12 * np.linalg.norm(g)
+
+
+def test_lbfgs_quadratic_and_rosenbrock():
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((20, 20))
+    A = A @ A.T + 20 * np.eye(20)
+    b = rng.standard_normal(20)
+    x, f, log = lbfgs(lambda x: (0.5 * x @ A @ x - b @ x, A @ x - b), np.zeros(20), maxiter=40, history=8,
+                      first_step=0.1)
+    assert np.linalg.norm(A @ x - b) < 1e-6 * np.linalg.norm(b)
+    assert all(log[i + 1]["f"] <= log[i]["f"] for i in range(len(log) - 1))
+
+    def rosen(x):
+        f = 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+        g = np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)])
+        return f, g
+
+    x, f, _ = lbfgs(rosen, np.array([-1.2, 1.0]), maxiter=200, history=10, first_step=0.1, max_ls=30)
+    assert f < 1e-8 and np.allclose(x, 1.0, atol=1e-3)
+
+
+def test_lbfgs_respects_bounds():
+    x, f, _ = lbfgs(lambda x: (float(np.sum((x - 3.0) ** 2)), 2 * (x - 3.0)), np.zeros(4), maxiter=20,
+                    first_step=1.0, bounds=(-1.0, 2.0))
+    assert np.allclose(x, 2.0)
+
+
+def test_small_inversion_reduces_misfit_with_oracle_engine():
+    """The whole outer loop (shots -> gradient -> L-BFGS) on a toy 2-D problem, CPU oracle engine."""
+    w = workloads.cfg3(0.0625, nshots=3)
+    wav = w.wavelet(np.float64)
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(3)]
+    e = OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml)
+    sh.model_data(e, w.c, shots)
+    _, _, log = lbfgs(lambda m: sh.misfit_and_gradient(e, m, shots), w.c_init, maxiter=4, history=4,
+                      first_step=30.0, bounds=(1000.0, 4000.0))
+    assert log[-1]["f"] < 0.5 * log[0]["f"]
