@@ -254,13 +254,15 @@ struct Impl {
         std::vector<int> start, col;
         std::vector<int64_t> sp, sc;
         std::vector<T> scu, scq;
-        if (ctx->kernel == K_STREAM) {  // counting sort of the entries by workgroup tile
-            const int ntile = stream_num_tiles(g, ctx->tune);
+        {  // counting sort of the entries by the step kernel's workgroup tile
+            const bool st = ctx->kernel == K_STREAM;
+            const int ntile = st ? stream_num_tiles(g, ctx->tune) : point_num_tiles(g);
             start.assign(ntile + 1, 0);
             std::vector<int> tile(n);
             for (int i = 0; i < n; ++i) {
                 const int32_t *t = idx + (size_t)i * g.ndim;
-                tile[i] = stream_tile_of(g, ctx->tune, t[0], t[1], t[2]);
+                const int z = t[0], y = (g.ndim == 3) ? t[1] : 0, x = t[g.ndim - 1];
+                tile[i] = st ? stream_tile_of(g, ctx->tune, z, y, x) : point_tile_of(g, z, y, x);
                 ++start[tile[i] + 1];
             }
             for (int k = 0; k < ntile; ++k) start[k + 1] += start[k];
@@ -308,10 +310,8 @@ struct Impl {
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         const T *amp = (const T *)ctx->amp;
-        // STREAM kernel: injection and sampling are fused into the step launch (sampling of
-        // step n rides on launch n+1, which reads that field anyway); POINT kernel: separate
-        // small launches.
-        const bool fused = ctx->kernel == K_STREAM;
+        // Injection and sampling are fused into the step launch: one launch per time step.
+        // The sampling of step n rides on launch n+1, which reads that field anyway.
         int cur = 0, prev_n = -1;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         for (int it = 0; it < nt; ++it) {
@@ -320,7 +320,7 @@ struct Impl {
             if (save_q) a.q_out = q_store + (size_t)n * g.npts;
             // lagged imaging: u_cur of adjoint step n is mu^{n+2}, which pairs with q^{n+1}
             if (image && n + 1 < nt) a.q_in = q_store + (size_t)(n + 1) * g.npts;
-            if (fused) {
+            {
                 if (inj.n > 0) {
                     a.inj_start = (const int *)inj.s_start;
                     a.inj_pidx = (const int64_t *)inj.s_pidx;
@@ -338,18 +338,11 @@ struct Impl {
                 }
             }
             HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, s));
-            if (!fused) {
-                HIPCHK(ctx, launch_inject<T>((T *)ctx->u[cur ^ 1], a.q_out, (const int64_t *)inj.pidx,
-                                             (const int64_t *)inj.cidx, (const T *)inj.cu,
-                                             (const T *)inj.cq, amp + (size_t)n * inj.n, inj.n, s));
-                HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur ^ 1], (const int64_t *)out.pidx,
-                                             series + (size_t)n * out.n, out_scale, out.n, s));
-            }
             prev_n = n;
             cur ^= 1;
         }
-        if (fused)  // the last step's field has no following launch to ride on
-            HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur], (const int64_t *)out.pidx,
+        // the last step's field has no following launch to ride on
+        HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur], (const int64_t *)out.pidx,
                                          series + (size_t)prev_n * out.n, out_scale, out.n, s));
         if (image)  // the last pairing: mu^1 with q^0
             HIPCHK(ctx, launch_image<T>(g, (const T *)ctx->u[cur], q_store, (T *)ctx->g_acc, s));

@@ -41,7 +41,7 @@ struct StepArgs {
     int npml;        // border width; with dz_scale lets the stream kernel form dz[z] without a load
     T dz_scale;      // sigma_max dt / (2 npml^2): d_z(z) = dz_scale * dist(z)^2
 
-    // Point operations fused into the stream kernel (all nullptr / 0 = none).
+    // Point operations fused into the step kernels (all nullptr / 0 = none).
     // Injection into u_next (and q_out): entries sorted by workgroup tile,
     // inj_start[tile] .. inj_start[tile + 1] is the tile's slice.
     const int *inj_start;
@@ -68,6 +68,10 @@ struct StreamTuning {
 int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x);
 int stream_num_tiles(const GridDesc &g, const StreamTuning &t);
 
+// Same for the point kernel (64 x 4 point workgroups).
+int point_tile_of(const GridDesc &g, int z, int y, int x);
+int point_num_tiles(const GridDesc &g);
+
 // True when the stream kernel supports this grid / dtype.
 bool stream_supported(const GridDesc &g, bool is_f32);
 StreamTuning stream_default_tuning(const GridDesc &g);
@@ -76,10 +80,6 @@ template <typename T>
 hipError_t launch_step(int kernel, const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t,
                        hipStream_t s);
 
-// u[pidx[i]] += coef_u[i] * amp[i];  q[cidx[i]] += coef_q[i] * amp[i] (if q != nullptr)
-template <typename T>
-hipError_t launch_inject(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
-                         const T *coef_q, const T *amp, int n, hipStream_t s);
 // out[i] = u[pidx[i]] * scale
 template <typename T>
 hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n, hipStream_t s);

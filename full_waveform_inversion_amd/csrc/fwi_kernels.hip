@@ -44,42 +44,64 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
 // on-device cross-check of it.
 // ---------------------------------------------------------------------------
 template <typename T, int R, int NDIM, bool SAVE_Q, bool IMAGE>
-__global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int nbx, int nby, int nblk) {
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((int)blockIdx.x >= nblk) {
+        // receiver sampling of the previous step's field (u_cur) rides along as extra workgroups
+        for (int i = ((int)blockIdx.x - nblk) * 256 + tid; i < a.nrec; i += ((int)gridDim.x - nblk) * 256)
+            a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
+        return;
+    }
+    const int bx = blockIdx.x % nbx;
+    const int t2 = blockIdx.x / nbx;
+    const int x = bx * 64 + threadIdx.x;
     int y, z;
     if (NDIM == 3) {
-        y = blockIdx.y * 4 + threadIdx.y;
-        z = blockIdx.z;
+        y = (t2 % nby) * 4 + threadIdx.y;
+        z = t2 / nby;
     } else {
         y = 0;
-        z = blockIdx.y * 4 + threadIdx.y;
+        z = t2 * 4 + threadIdx.y;
     }
-    if (x >= g.nx || y >= g.ny || z >= g.nz) return;
-    const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
-    const T *u = a.u_cur + p;
-    const T uc = u[0];
-    T lap = T(0);
+    if (x < g.nx && y < g.ny && z < g.nz) {
+        const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
+        const T *u = a.u_cur + p;
+        const T uc = u[0];
+        T lap = T(0);
 #pragma unroll
-    for (int k = R; k >= 1; --k) {
-        T t = (u[-k] + u[k]) + (u[-(int64_t)k * g.sz] + u[(int64_t)k * g.sz]);
-        if (NDIM == 3) t += (u[-(int64_t)k * g.sy] + u[(int64_t)k * g.sy]);
-        t = fma(T(-2 * NDIM), uc, t);
-        lap = fma(a.ck[k], t, lap);
+        for (int k = R; k >= 1; --k) {
+            T t = (u[-k] + u[k]) + (u[-(int64_t)k * g.sz] + u[(int64_t)k * g.sz]);
+            if (NDIM == 3) t += (u[-(int64_t)k * g.sy] + u[(int64_t)k * g.sy]);
+            t = fma(T(-2 * NDIM), uc, t);
+            lap = fma(a.ck[k], t, lap);
+        }
+        const T q = a.C[p] * lap;
+        const T up = a.u_prev[p];
+        T un;
+        if (a.damp) {
+            T d = a.dz[z] + a.dx[x];
+            if (NDIM == 3) d += a.dy[y];
+            un = (T(2) * uc - (T(1) - d) * up + q) / (T(1) + d);
+        } else {
+            un = (T(2) * uc - up) + q;
+        }
+        a.u_prev[p] = un;
+        const int64_t ci = ((int64_t)z * g.ny + y) * g.nx + x;
+        if (SAVE_Q) a.q_out[ci] = q;
+        if (IMAGE) a.g[ci] += uc * a.q_in[ci];
     }
-    const T q = a.C[p] * lap;
-    const T up = a.u_prev[p];
-    T un;
-    if (a.damp) {
-        T d = a.dz[z] + a.dx[x];
-        if (NDIM == 3) d += a.dy[y];
-        un = (T(2) * uc - (T(1) - d) * up + q) / (T(1) + d);
-    } else {
-        un = (T(2) * uc - up) + q;
+    // injection into the points this workgroup has just written (see the stream kernel)
+    if (a.inj_start) {
+        const int s0 = a.inj_start[blockIdx.x], s1 = a.inj_start[blockIdx.x + 1];
+        if (s1 > s0) {
+            __syncthreads();
+            for (int i = s0 + tid; i < s1; i += 256) {
+                const T amp = a.inj_amp[a.inj_col[i]];
+                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
+                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
+            }
+        }
     }
-    a.u_prev[p] = un;
-    const int64_t ci = ((int64_t)z * g.ny + y) * g.nx + x;
-    if (SAVE_Q) a.q_out[ci] = q;
-    if (IMAGE) a.g[ci] += uc * a.q_in[ci];
 }
 
 // ---------------------------------------------------------------------------
@@ -405,16 +427,36 @@ static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, c
     }
 }
 
+static inline void point_blocks(const GridDesc &g, int &nbx, int &nby, int &nblk) {
+    nbx = (g.nx + 63) / 64;
+    nby = (g.ndim == 3) ? (g.ny + 3) / 4 : (g.nz + 3) / 4;
+    nblk = nbx * nby * ((g.ndim == 3) ? g.nz : 1);
+}
+
+int point_tile_of(const GridDesc &g, int z, int y, int x) {
+    int nbx, nby, nblk;
+    point_blocks(g, nbx, nby, nblk);
+    return (g.ndim == 3) ? (z * nby + y / 4) * nbx + x / 64 : (z / 4) * nbx + x / 64;
+}
+
+int point_num_tiles(const GridDesc &g) {
+    int nbx, nby, nblk;
+    point_blocks(g, nbx, nby, nblk);
+    return nblk;
+}
+
 template <typename T, int R, int NDIM>
 static hipError_t launch_point_mode(const GridDesc &g, const StepArgs<T> &a, hipStream_t s) {
-    dim3 block(64, 4);
-    dim3 grid((g.nx + 63) / 64, NDIM == 3 ? (g.ny + 3) / 4 : (g.nz + 3) / 4, NDIM == 3 ? g.nz : 1);
+    int nbx, nby, nblk;
+    point_blocks(g, nbx, nby, nblk);
+    const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 1023) / 1024 : 0;
+    dim3 block(64, 4), grid(nblk + nrb);
     if (a.q_out)
-        hipLaunchKernelGGL((step_point<T, R, NDIM, true, false>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step_point<T, R, NDIM, true, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step_point<T, R, NDIM, false, true>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, true>), grid, block, 0, s, a, g, nbx, nby, nblk);
     else
-        hipLaunchKernelGGL((step_point<T, R, NDIM, false, false>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
     return hipGetLastError();
 }
 
@@ -454,31 +496,12 @@ hipError_t launch_step<double>(int, const GridDesc &g, const StepArgs<double> &a
 }
 
 // ---------------------------------------------------------------------------
-// Point operations: source / residual injection and receiver sampling.
+// Receiver sampling of the final step (earlier steps are sampled inside the step launches).
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ void inject_kernel(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
-                              const T *coef_q, const T *amp, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const T a = amp[i];
-    atomicAdd(u + pidx[i], coef_u[i] * a);  // atomics: several points may share a node
-    if (q) atomicAdd(q + cidx[i], coef_q[i] * a);
-}
-
 template <typename T>
 __global__ void record_kernel(const T *u, const int64_t *pidx, T *out, T scale, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = u[pidx[i]] * scale;
-}
-
-template <typename T>
-hipError_t launch_inject(T *u, T *q, const int64_t *pidx, const int64_t *cidx, const T *coef_u,
-                         const T *coef_q, const T *amp, int n, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(inject_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, s, u, q, pidx, cidx, coef_u,
-                       coef_q, amp, n);
-    return hipGetLastError();
 }
 
 template <typename T>
@@ -558,8 +581,6 @@ hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_
 }
 
 #define FWI_INSTANTIATE(T)                                                                          \
-    template hipError_t launch_inject<T>(T *, T *, const int64_t *, const int64_t *, const T *,    \
-                                         const T *, const T *, int, hipStream_t);                  \
     template hipError_t launch_record<T>(const T *, const int64_t *, T *, T, int, hipStream_t);    \
     template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
     template hipError_t launch_finalize_gradient<T>(const T *, const T *, T *, double, int, int64_t, \
