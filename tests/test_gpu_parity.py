@@ -248,24 +248,28 @@ def test_single_rank_rccl_allreduce(gpu):
 # shot loop + optimiser on the real engine (BASELINE configs[2] / [4], scaled)
 # ---------------------------------------------------------------------------
 def test_shot_loop_gradient_vs_oracle(gpu):
-    """cfg3 scaled: 4 shots, summed misfit and gradient at the smoothed start model."""
+    """cfg3 scaled: 4 shots, summed misfit and gradient at the smoothed start model.
+
+    End to end (observed data is the shared INPUT, each path forms its own residual): the
+    fp32 forward error (~1e-6 of |d|, see tools/parity_report.py) enters the residual
+    amplified by |d| / |r| (about 15 here), so the bar is 1e-4, not the 1e-5 that holds for
+    the seismograms and for the gradient of a given residual (test_baseline_configs_scaled).
+    """
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from _oracle_engine import OracleEngine
     from full_waveform_inversion_amd import shots as sh
 
     w = workloads.cfg3(0.125, nshots=4)  # 128 x 128, 250 steps
-    res = []
-    for make, dt in ((lambda **k: OracleEngine(w.shape, w.h, w.dt, w.nt, **k), np.float64),
-                     (lambda **k: Engine(w.shape, w.h, w.dt, w.nt, **k), np.float32)):
-        wav = w.wavelet(dt)
-        shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
-        e = make(order=w.order, npml=w.npml, sigma_max=res[0][2] if res else None)
-        sh.model_data(e, w.c, shots)
-        J, g = sh.misfit_and_gradient(e, w.c_init, shots)
-        res.append((J, g, e.sigma_max))
-    assert abs(res[1][0] - res[0][0]) < 1e-5 * res[0][0]
-    assert rel(res[1][1], res[0][1]) < TOL32
+    wav = w.wavelet(np.float64)
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
+    o = OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml)
+    sh.model_data(o, w.c, shots)
+    J0, g0 = sh.misfit_and_gradient(o, w.c_init, shots)
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=o.sigma_max) as e:
+        J1, g1 = sh.misfit_and_gradient(e, w.c_init, shots)
+    assert abs(J1 - J0) < 1e-4 * J0
+    assert rel(g1, g0) < 1e-4
 
 
 def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
