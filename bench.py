@@ -98,7 +98,9 @@ def main():
     model = w.c.astype(np.float32)
     e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local, kernel=args.kernel,
                zchunk=args.zchunk)
+    t_sm = time.perf_counter()
     e.set_model(model)
+    set_model_ms = 1e3 * (time.perf_counter() - t_sm)  # host padding + H2D, once per model (not timed)
     if world > 1:
         ids = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -140,7 +142,7 @@ def main():
             "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic", "set_model_ms": round(set_model_ms, 1),
             "config": {"workload": "configs[3]: 3-D %s constant velocity, 1 shot/GPU/step, %d time steps, "
                                    "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
                        "kernel": e.kernel_name, "parallelism": "shot-parallel x%d" % world,
