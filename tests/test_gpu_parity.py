@@ -252,8 +252,9 @@ def test_shot_loop_gradient_vs_oracle(gpu):
 
     End to end (observed data is the shared INPUT, each path forms its own residual): the
     fp32 forward error (~1e-6 of |d|, see tools/parity_report.py) enters the residual
-    amplified by |d| / |r| (about 15 here), so the bar is 1e-4, not the 1e-5 that holds for
-    the seismograms and for the gradient of a given residual (test_baseline_configs_scaled).
+    amplified by |d| / |r|, so the bar is scaled by that measured ratio instead of the flat
+    1e-5 that holds for the seismograms and for the gradient of a given residual
+    (test_baseline_configs_scaled).
     """
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -265,11 +266,14 @@ def test_shot_loop_gradient_vs_oracle(gpu):
     shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
     o = OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml)
     sh.model_data(o, w.c, shots)
-    J0, g0 = sh.misfit_and_gradient(o, w.c_init, shots)
+    c0 = 0.97 * w.c_init  # start model 3 % slow: a residual comparable to the data
+    J0, g0 = sh.misfit_and_gradient(o, c0, shots)
+    amp = np.sqrt(sum(np.sum(s.d_obs ** 2) for s in shots) / (2 * J0))  # |d| / |r|
     with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=o.sigma_max) as e:
-        J1, g1 = sh.misfit_and_gradient(e, w.c_init, shots)
-    assert abs(J1 - J0) < 1e-4 * J0
-    assert rel(g1, g0) < 1e-4
+        J1, g1 = sh.misfit_and_gradient(e, c0, shots)
+    assert amp < 10
+    assert abs(J1 - J0) < 2 * TOL32 * amp * J0
+    assert rel(g1, g0) < TOL32 * amp
 
 
 def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
