@@ -499,7 +499,8 @@ const char *fwi_last_error(const fwi_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 const char *fwi_kernel_name(const fwi_ctx *ctx) {
     if (!ctx) return "";
-    return ctx->kernel == K_STREAM ? "step3d_stream" : "step_point";
+    if (ctx->kernel == K_STREAM) return ctx->gd.ndim == 3 ? "step3d_stream" : "step2d_tile";
+    return "step_point";
 }
 
 int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
@@ -540,7 +541,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
-        return bad("STREAM kernel needs a 3-D fp32 grid with nx % 4 == 0");
+        return bad("STREAM kernel needs an fp32 grid with nx % 4 == 0");
     }
     ctx->kernel = (cfg->kernel == FWI_KERNEL_POINT || !can_stream) ? K_POINT : K_STREAM;
     if (ctx->kernel == K_STREAM) {
@@ -548,7 +549,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
         if (const char *ty = getenv("FWI_STREAM_TY")) {  // tuning hook: rows per workgroup
             const int v = atoi(ty);
-            if (v == 4 || v == 8) ctx->tune.ty = v;
+            if (v == 4 || v == 8 || (v == 16 && cfg->ndim == 2)) ctx->tune.ty = v;
         }
     }
     int rc = create_impl(ctx);

@@ -32,7 +32,8 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     const int64_t py = (ndim == 3) ? HALO + round_up(g.ny, YALIGN) + HALO : 1;
     g.sz = g.sy * py;
     g.off0 = (int64_t)HALO * g.sz + (int64_t)hy * g.sy + HALO;
-    g.ptot = g.sz * (int64_t)(nz + 2 * HALO);
+    // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D
+    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz) + 2 * HALO);
     g.npts = (int64_t)nz * g.ny * nx;
     return g;
 }
@@ -350,22 +351,146 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     }
 }
 
+// ---------------------------------------------------------------------------
+// TILE kernel (2-D, fp32): the 2-D sibling of the stream kernel.  A workgroup of 64 x TY threads
+// owns a 256 x TY (x, z) tile, one float4 per thread; the TY + 2r rows it needs are staged in LDS
+// once (one barrier), x neighbours come from the same LDS row.  2-D grids of BASELINE size are
+// L2-resident (1024^2: 4 MiB per field), so a time step is bounded by the ~1.5 us kernel boundary
+// plus one load -> barrier -> compute -> store chain; there is no marching axis to pipeline.
+// ---------------------------------------------------------------------------
+template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE>
+__global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDesc g, int nxt, int nblk) {
+    constexpr int NH = (2 * R + TY - 1) / TY;
+    constexpr int TRASH = TY + 2 * R;
+    constexpr int LROWS = TY + 2 * R + 1;
+    __shared__ f4 L[LROWS][LROW4];
+
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    int bid = blockIdx.x;
+    if (bid >= nblk) {  // receiver sampling of the previous step's field
+        for (int i = (bid - nblk) * (64 * TY) + ty * 64 + lane; i < a.nrec; i += (gridDim.x - nblk) * 64 * TY)
+            a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
+        return;
+    }
+    const int bx = bid % nxt, bz = bid / nxt;
+    const int x0 = bx * TILE_X + 4 * lane;
+    const int z0 = bz * TY, z = z0 + ty;
+    const bool act = (x0 < g.nx) && (z < g.nz);
+    const int64_t sz = g.sz;
+    const int64_t poff = g.off0 + (int64_t)z * sz + x0;
+
+    const f4 ctr = ld4(a.u_cur + poff);
+    f4 halo[NH];
+    int hrow[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hr = ty + i * TY;
+        const bool valid = hr < 2 * R;
+        const int zh = !valid ? z : (hr < R) ? z0 - R + hr : z0 + TY + (hr - R);
+        hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
+        halo[i] = ld4(a.u_cur + g.off0 + (int64_t)zh * sz + x0);
+    }
+    const int64_t rowoff = g.off0 + (int64_t)z * sz + bx * TILE_X;
+    const int64_t eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
+    const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : 4 + 4 * lane;
+    const float edge = a.u_cur[eoff];
+    const f4 up = ld4(a.u_prev + poff), Cc = ld4(a.C + poff);
+    const int64_t ci = (int64_t)z * g.nx + x0;
+    f4 qi, gi;
+    if (IMAGE) {
+        qi = ld4_stream(a.q_in + (act ? ci : 0));
+        gi = ld4(a.g + (act ? ci : 0));
+    }
+    f4 A, B;
+    if (DAMP) {
+        const float dzv = (z < g.nz) ? a.dz[z] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = dzv + ((x0 + j < g.nx) ? a.dx[x0 + j] : 0.f);
+            B.v[j] = 1.f - d;
+            A.v[j] = rcp_nr(1.f + d);
+        }
+    }
+
+    L[R + ty][1 + lane] = ctr;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[i];
+    reinterpret_cast<float *>(&L[erow][0])[ecol] = edge;
+    __syncthreads();
+
+    const f4 xl = L[R + ty][lane], xr = L[R + ty][lane + 2];
+    float X[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        X[j] = xl.v[j];
+        X[4 + j] = ctr.v[j];
+        X[8 + j] = xr.v[j];
+    }
+    f4 lap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lap.v[j] = 0.f;
+#pragma unroll
+    for (int k = R; k >= 1; --k) {
+        const f4 zm = L[R + ty - k][1 + lane], zp = L[R + ty + k][1 + lane];
+        const float c = a.ck[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = (X[4 + j - k] + X[4 + j + k]) + (zm.v[j] + zp.v[j]);
+            t = fmaf(-4.f, X[4 + j], t);
+            lap.v[j] = fmaf(c, t, lap.v[j]);
+        }
+    }
+    f4 q, un;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        q.v[j] = Cc.v[j] * lap.v[j];
+        if (DAMP)
+            un.v[j] = (fmaf(2.f, X[4 + j], -B.v[j] * up.v[j]) + q.v[j]) * A.v[j];
+        else
+            un.v[j] = (2.f * X[4 + j] - up.v[j]) + q.v[j];
+    }
+    if (act) {
+        st4(a.u_prev + poff, un);
+        if (SAVE_Q) st4_stream(a.q_out + ci, q);
+        if (IMAGE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+            st4(a.g + ci, gi);
+        }
+    }
+    if (a.inj_start) {  // injection into the points this workgroup has just written
+        const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
+        if (s1 > s0) {
+            __syncthreads();
+            for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
+                const float amp = a.inj_amp[a.inj_col[i]];
+                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
+                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
+            }
+        }
+    }
+}
+
 static inline int stream_nxt(const GridDesc &g) { return (int)(round_up(g.nx, TILE_X) / TILE_X); }
 
 int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x) {
+    if (g.ndim == 2) return (z / t.ty) * stream_nxt(g) + x / TILE_X;
     const int nxt = stream_nxt(g), nyt = (g.ny + t.ty - 1) / t.ty;
     return ((z / t.zchunk) * nyt + y / t.ty) * nxt + x / TILE_X;
 }
 
 int stream_num_tiles(const GridDesc &g, const StreamTuning &t) {
+    if (g.ndim == 2) return stream_nxt(g) * ((g.nz + t.ty - 1) / t.ty);
     return stream_nxt(g) * ((g.ny + t.ty - 1) / t.ty) * ((g.nz + t.zchunk - 1) / t.zchunk);
 }
 
 bool stream_supported(const GridDesc &g, bool is_f32) {
-    return is_f32 && g.ndim == 3 && (g.nx % 4 == 0) && g.nz >= 1;
+    return is_f32 && (g.nx % 4 == 0) && g.nz >= 1;
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g) {
+    if (g.ndim == 2) return StreamTuning{8, 1};  // rows per workgroup; no marching axis
     // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
     // (about one per CU, 256 CUs) each marching as many planes as possible, because every
     // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
@@ -427,6 +552,38 @@ static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, c
     }
 }
 
+template <int R, int TY, bool DAMP>
+static hipError_t launch_tile2d_mode(const GridDesc &g, const StepArgs<float> &a, hipStream_t s) {
+    const int nxt = stream_nxt(g);
+    const int nblk = nxt * ((g.nz + TY - 1) / TY);
+    const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
+    dim3 block(64, TY), grid(nblk + nrb);
+    if (a.q_out)
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, true, false>), grid, block, 0, s, a, g, nxt, nblk);
+    else if (a.q_in)
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, true>), grid, block, 0, s, a, g, nxt, nblk);
+    else
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, false>), grid, block, 0, s, a, g, nxt, nblk);
+    return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_tile2d_r(const GridDesc &g, const StepArgs<float> &a, const StreamTuning &t,
+                                  hipStream_t s) {
+    if (a.damp) {
+        switch (t.ty) {
+            case 4: return launch_tile2d_mode<R, 4, true>(g, a, s);
+            case 16: return launch_tile2d_mode<R, 16, true>(g, a, s);
+            default: return launch_tile2d_mode<R, 8, true>(g, a, s);
+        }
+    }
+    switch (t.ty) {
+        case 4: return launch_tile2d_mode<R, 4, false>(g, a, s);
+        case 16: return launch_tile2d_mode<R, 16, false>(g, a, s);
+        default: return launch_tile2d_mode<R, 8, false>(g, a, s);
+    }
+}
+
 static inline void point_blocks(const GridDesc &g, int &nbx, int &nby, int &nblk) {
     nbx = (g.nx + 63) / 64;
     nby = (g.ndim == 3) ? (g.ny + 3) / 4 : (g.nz + 3) / 4;
@@ -479,6 +636,13 @@ static hipError_t launch_point(const GridDesc &g, const StepArgs<T> &a, hipStrea
 template <>
 hipError_t launch_step<float>(int kernel, const GridDesc &g, const StepArgs<float> &a,
                               const StreamTuning &t, hipStream_t s) {
+    if (kernel == K_STREAM && g.ndim == 2) {
+        switch (g.r) {
+            case 1: return launch_tile2d_r<1>(g, a, t, s);
+            case 2: return launch_tile2d_r<2>(g, a, t, s);
+            default: return launch_tile2d_r<4>(g, a, t, s);
+        }
+    }
     if (kernel == K_STREAM) {
         switch (g.r) {
             case 1: return launch_stream_r<1>(g, a, t, s);

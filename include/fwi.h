@@ -44,7 +44,8 @@ enum { FWI_F32 = 0, FWI_F64 = 1 };
 enum {
     FWI_KERNEL_AUTO = 0,
     FWI_KERNEL_POINT = 1,  /* one thread per grid point, neighbours through L1/L2 */
-    FWI_KERNEL_STREAM = 2  /* 3-D: z-marching register queue + LDS-staged xy halo tile */
+    FWI_KERNEL_STREAM = 2  /* fp32 float4 kernels with LDS-staged halo tiles: 3-D z-marching
+                              register queue (step3d_stream) / 2-D row tiles (step2d_tile) */
 };
 
 enum { FWI_WRT_VELOCITY = 0, FWI_WRT_SLOWNESS2 = 1 };
@@ -70,7 +71,7 @@ typedef struct fwi_config {
     int32_t device;      /* HIP device ordinal */
     int32_t dtype;       /* FWI_F32 or FWI_F64 */
     int32_t kernel;      /* FWI_KERNEL_* */
-    int32_t zchunk;      /* STREAM kernel: planes marched per workgroup; 0 = auto */
+    int32_t zchunk;      /* 3-D STREAM kernel: planes marched per workgroup; 0 = auto */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the sponge, >= 0 (used when npml > 0) */
