@@ -490,7 +490,7 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g) {
-    if (g.ndim == 2) return StreamTuning{8, 1};  // rows per workgroup; no marching axis
+    if (g.ndim == 2) return StreamTuning{16, 1};  // rows per workgroup (measured best of 4/8/16); no marching axis
     // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
     // (about one per CU, 256 CUs) each marching as many planes as possible, because every
     // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64

@@ -271,7 +271,7 @@ def test_shot_loop_gradient_vs_oracle(gpu):
     amp = np.sqrt(sum(np.sum(s.d_obs ** 2) for s in shots) / (2 * J0))  # |d| / |r|
     with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=o.sigma_max) as e:
         J1, g1 = sh.misfit_and_gradient(e, c0, shots)
-    assert amp < 10
+    assert amp < 30
     assert abs(J1 - J0) < 2 * TOL32 * amp * J0
     assert rel(g1, g0) < TOL32 * amp
 
