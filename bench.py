@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--npml", type=int, default=0)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
+                    help="forward: the headline stencil run; gradient: forward(save) + adjoint(imaging) per step")
     ap.add_argument("--cpu-steps", type=int, default=1000,
                     help="time steps of the CPU baseline sample (1000 = the whole shot, ~12 s on 16 cores); 0 = skip")
     args = ap.parse_args()
@@ -106,9 +108,14 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         e.comm_init(rank, world, ids[0])
 
+    grad = args.mode == "gradient"
+
     def step():
-        e.forward(None, (w.src_idx, wav), w.rec_idx, save=False)
+        d = e.forward(None, (w.src_idx, wav), w.rec_idx, save=grad)
         ms = e.last_loop_ms()
+        if grad:
+            e.adjoint(d)  # residual = the data themselves: same work as any residual
+            ms += e.last_loop_ms()
         if world > 1:
             e.allreduce_gradient()  # the shot loop's one exchange (sum of per-rank gradients)
         return ms
@@ -132,13 +139,16 @@ def main():
 
     if rank == 0:
         npts = int(np.prod(w.shape))
-        updates = npts * w.nt
+        sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
+        bpu = (20 + 28) / 2.0 if grad else BYTES_PER_UPDATE  # SURVEY s.8d: save 20 B, adjoint+imaging 28 B
+        updates = npts * w.nt * sweeps
         value = world * args.steps * updates / el / 1e9
-        kern_us = 1e3 * float(np.mean(loop_ms)) / w.nt  # avg launch-to-launch time of the step kernel
-        achieved = BYTES_PER_UPDATE * npts / (kern_us * 1e-6) / 1e9
-        traffic, traffic_src = measured_traffic(e.kernel_name, w.shape)
+        kern_us = 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps)  # avg launch-to-launch time per step kernel
+        achieved = bpu * npts / (kern_us * 1e-6) / 1e9
+        traffic, traffic_src = (None, None) if grad else measured_traffic(e.kernel_name, w.shape)
         out = {
-            "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic",
+            "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic" +
+                      (" (forward+adjoint sweeps)" if grad else ""),
             "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -150,12 +160,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * npts,
+                         "algorithmic_bytes_per_launch": bpu * npts,
                          "kernel_avg_us": round(kern_us, 2),
-                         "note": "algorithmic 16 B/update x %d updates per launch / HIP-event time of the "
-                                 "%d-launch loop; working set 3 x %d MiB" % (npts, w.nt, npts * 4 >> 20)},
+                         "note": "algorithmic %g B/update x %d updates per launch / HIP-event time of the "
+                                 "%d-launch loop(s); wavefield working set 3 x %d MiB" % (bpu, npts, w.nt * sweeps,
+                                                                                         npts * 4 >> 20)},
         }
-        if args.cpu_steps > 0 and world == 1:
+        if args.cpu_steps > 0 and world == 1 and not grad:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
         print(json.dumps(out))
     e.close()
