@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -59,7 +59,11 @@ SIGNATURES = {
     "fwi_synchronize": (C.c_int, [_P]),
     "fwi_kernel_name": (C.c_char_p, [_P]),
     "fwi_device_count": (C.c_int, [C.POINTER(_I32)]),
+    "fwi_mc_score": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P,
+                               C.POINTER(_D)]),
+    "fwi_mc_forward": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P]),
 }
+MC_METRICS = {"VR": 0, "CC": 1, "PCC": 2, "CC-shift": 3, "gau": 4}
 
 _lib = None
 

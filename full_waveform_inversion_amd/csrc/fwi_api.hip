@@ -717,3 +717,163 @@ int fwi_synchronize(fwi_ctx *ctx) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The reference's real hot loop: batched scoring of source samples.
+// ---------------------------------------------------------------------------------------------
+namespace fwi {
+hipError_t launch_mc_score(const double *G, const double *d, const double *Ms, const double *dmom, int k, int n,
+                           int t, int64_t nsamp, int metric, int normalise, int all_at_once, double gau_sigma,
+                           double *sim, double *like, hipStream_t s);
+hipError_t launch_mc_forward(const double *G, const double *Ms, int k, int n, int t, int64_t nsamp, double *synth,
+                             hipStream_t s);
+size_t mc_score_lds_bytes(int k, int n);
+}  // namespace fwi
+
+namespace {
+
+struct DevBuf {  // frees on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+int mc_fail(int code, const char *what, hipError_t e) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+    return code;
+}
+
+#define MCCHK(call)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return mc_fail(e_ == hipErrorOutOfMemory ? FWI_ENOMEM : FWI_EHIP, #call, e_); \
+    } while (0)
+
+int mc_check_args(const char *fn, int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const void *a,
+                  const void *b, const void *c) {
+    if (k < 1 || n < 1 || t < 1 || nsamp < 1 || !a || !b || !c) {
+        g_create_error = std::string(fn) + ": bad argument";
+        return FWI_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        g_create_error = std::string(fn) + ": no HIP device available (this library has no CPU fallback)";
+        return FWI_EHIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = std::string(fn) + ": device ordinal out of range";
+        return FWI_EINVAL;
+    }
+    return FWI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
+                 const double *data, const double *samples, int32_t metric, int32_t normalise,
+                 int32_t all_at_once, double *similarity_out, double *likelihood_out, double *posterior_out,
+                 double *kernel_ms_out) {
+    int rc = mc_check_args("fwi_mc_score", device, k, n, t, nsamp, green, data, samples);
+    if (rc) return rc;
+    if (!similarity_out || metric < FWI_MC_VR || metric > FWI_MC_GAU) {
+        g_create_error = "fwi_mc_score: bad metric or null output";
+        return FWI_EINVAL;
+    }
+    if (fwi::mc_score_lds_bytes(k, n) > 64 * 1024) {
+        g_create_error = "fwi_mc_score: k * n too large for the per-workgroup moment table";
+        return FWI_EINVAL;
+    }
+    MCCHK(hipSetDevice(device));
+    // data-only moments per trace (sum d, sum d^2, max|d|, sum d_i d_{i+1}, first, last) and the
+    // noise level of gaussian_comparison (:580): mean |flattened (normalised) data[-60:-10]|
+    std::vector<double> dmom((size_t)k * 6);
+    for (int kk = 0; kk < k; ++kk) {
+        const double *dk = data + (size_t)kk * t;
+        double s1 = 0, s2 = 0, mx = 0, dd1 = 0;
+        for (int e = 0; e < t; ++e) {
+            s1 += dk[e];
+            s2 += dk[e] * dk[e];
+            mx = std::max(mx, std::fabs(dk[e]));
+            if (e + 1 < t) dd1 += dk[e] * dk[e + 1];
+        }
+        double *m = &dmom[(size_t)kk * 6];
+        m[0] = s1; m[1] = s2; m[2] = mx; m[3] = dd1; m[4] = dk[0]; m[5] = dk[t - 1];
+    }
+    double sigma = 0.0;
+    {
+        const int64_t len = (int64_t)k * t;  // numpy slice [-60:-10] of the flattened array
+        const int64_t lo = std::max<int64_t>(0, len - 60), hi = std::max<int64_t>(0, len - 10);
+        double acc = 0.0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const double v = data[i];
+            acc += std::fabs(normalise ? v / dmom[(size_t)(i / t) * 6 + 2] : v);
+        }
+        sigma = (hi > lo) ? acc / (double)(hi - lo) : NAN;
+    }
+    hipStream_t s = nullptr;  // default stream: this call is synchronous
+    DevBuf G, d, M, dm, sim, like;
+    const size_t gb = (size_t)k * n * t * 8, db = (size_t)k * t * 8, mb = (size_t)n * nsamp * 8, sb = (size_t)nsamp * 8;
+    MCCHK(hipMalloc(&G.p, gb));
+    MCCHK(hipMalloc(&d.p, db));
+    MCCHK(hipMalloc(&M.p, mb));
+    MCCHK(hipMalloc(&dm.p, dmom.size() * 8));
+    MCCHK(hipMalloc(&sim.p, sb));
+    MCCHK(hipMalloc(&like.p, sb));
+    MCCHK(hipMemcpy(G.p, green, gb, hipMemcpyHostToDevice));
+    MCCHK(hipMemcpy(d.p, data, db, hipMemcpyHostToDevice));
+    MCCHK(hipMemcpy(M.p, samples, mb, hipMemcpyHostToDevice));
+    MCCHK(hipMemcpy(dm.p, dmom.data(), dmom.size() * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    MCCHK(hipEventCreate(&e0));
+    MCCHK(hipEventCreate(&e1));
+    MCCHK(hipEventRecord(e0, s));
+    hipError_t le = fwi::launch_mc_score((const double *)G.p, (const double *)d.p, (const double *)M.p,
+                                         (const double *)dm.p, k, n, t, nsamp, metric, normalise != 0,
+                                         all_at_once != 0, sigma, (double *)sim.p, (double *)like.p, s);
+    if (le != hipSuccess) return mc_fail(FWI_EHIP, "mc_score_kernel launch", le);
+    MCCHK(hipEventRecord(e1, s));
+    MCCHK(hipMemcpy(similarity_out, sim.p, sb, hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    MCCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (kernel_ms_out) *kernel_ms_out = ms;
+    if (likelihood_out || posterior_out) {
+        std::vector<double> tmp;
+        double *L = likelihood_out;
+        if (!L) {
+            tmp.resize(nsamp);
+            L = tmp.data();
+        }
+        MCCHK(hipMemcpy(L, like.p, sb, hipMemcpyDeviceToHost));
+        if (posterior_out) {  // :847-848, p_model = 1/N
+            const double p_model = 1.0 / (double)nsamp;
+            double p_data = 0.0;
+            for (int64_t i = 0; i < nsamp; ++i) p_data += p_model * L[i];
+            for (int64_t i = 0; i < nsamp; ++i) posterior_out[i] = L[i] * p_model / p_data;
+        }
+    }
+    return FWI_OK;
+}
+
+int fwi_mc_forward(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
+                   const double *samples, double *synth_out) {
+    int rc = mc_check_args("fwi_mc_forward", device, k, n, t, nsamp, green, samples, synth_out);
+    if (rc) return rc;
+    MCCHK(hipSetDevice(device));
+    DevBuf G, M, S;
+    const size_t gb = (size_t)k * n * t * 8, mb = (size_t)n * nsamp * 8, sb = (size_t)nsamp * k * t * 8;
+    MCCHK(hipMalloc(&G.p, gb));
+    MCCHK(hipMalloc(&M.p, mb));
+    MCCHK(hipMalloc(&S.p, sb));
+    MCCHK(hipMemcpy(G.p, green, gb, hipMemcpyHostToDevice));
+    MCCHK(hipMemcpy(M.p, samples, mb, hipMemcpyHostToDevice));
+    hipError_t le = fwi::launch_mc_forward((const double *)G.p, (const double *)M.p, k, n, t, nsamp,
+                                           (double *)S.p, nullptr);
+    if (le != hipSuccess) return mc_fail(FWI_EHIP, "mc_forward_kernel launch", le);
+    MCCHK(hipMemcpy(synth_out, S.p, sb, hipMemcpyDeviceToHost));
+    return FWI_OK;
+}
+
+}  // extern "C"

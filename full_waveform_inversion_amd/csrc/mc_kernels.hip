@@ -1,0 +1,262 @@
+// The reference's REAL hot loop on gfx950: batched forward_model + similarity metric + likelihood
+// for N source samples (full_waveform_inversion.py:713-774).
+//
+//   forward_model (:253-264)            synth[k,t] = sum_j G[k,j,t] * M[j]
+//   compare_synth_to_real_waveforms     (:584-684) optional per-trace max-abs normalisation, then
+//     variance_reduction (:512), cross_corr_comparison (:534), pearson_correlation_comparison (:568),
+//     cross_corr_comparison_shift_allowed (:548), gaussian_comparison (:578), per trace or flattened
+//   likelihood exp(-(1-s)/2) (:774)
+//
+// fp64 like the reference.  One 256-thread workgroup scores SPB samples at once: each thread streams
+// its time samples of G (L2-resident, read once per workgroup, reused for SPB samples in registers),
+// forms the synthetic on the fly and accumulates raw moments per (sample, trace); moments are reduced
+// with wave64 shuffles + LDS, and one thread per sample evaluates the metric in closed form from the
+// moments (the synthetic is never written).  CC-shift uses the exact sums of the 4x linearly
+// interpolated sequences (np.interp clamps past the last sample), expressed through lag-1 products.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fwi {
+
+constexpr int SPB = 4;        // samples per workgroup
+constexpr int MC_THREADS = 256;
+// moments per (sample, trace)
+enum { M_S1 = 0, M_S2, M_DS, M_MAX, M_SS1, M_DS1, M_D1S, M_FIRST, M_LAST, NMOM };
+// data-only moments per trace (host computed): sum d, sum d^2, max|d|, sum d_i d_{i+1}, d_first, d_last
+enum { D_1 = 0, D_2, D_MAX, D_DD1, D_FIRST, D_LAST, NDMOM };
+
+enum { MC_VR = 0, MC_CC = 1, MC_PCC = 2, MC_CCSHIFT = 3, MC_GAU = 4 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+struct SeqMom {  // moments of a pair of (possibly upsampled) sequences of common length len
+    double sx, sy, sxx, syy, sxy, len;
+};
+
+__device__ __forceinline__ double corr_from(const SeqMom &m) {  // Pearson r == the reference's CC
+    const double mx = m.sx / m.len, my = m.sy / m.len;
+    const double cov = m.sxy / m.len - mx * my;
+    const double vx = m.sxx / m.len - mx * mx, vy = m.syy / m.len - my * my;
+    const double r = cov / (sqrt(vx) * sqrt(vy));
+    return r < 0.0 ? 0.0 : r;  // NaN (zero variance) propagates like in the reference
+}
+
+// sums of the 4x interpolated sequence built from a plain sequence described by its moments
+__device__ __forceinline__ double up_sum(double s1, double first, double last) {
+    return 2.5 * (s1 - last) + 1.5 * (s1 - first) + 4.0 * last;
+}
+__device__ __forceinline__ double up_dot(double p0, double p1, double p1r, double x0y0, double xLyL) {
+    return 1.875 * (p0 - xLyL) + 0.875 * (p0 - x0y0) + 0.625 * (p1 + p1r) + 4.0 * xLyL;
+}
+
+template <bool LAG>
+__global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
+    const double *__restrict__ G, const double *__restrict__ d, const double *__restrict__ Ms,
+    const double *__restrict__ dmom, int k, int n, int t, int64_t nsamp, int metric, int normalise,
+    int all_at_once, double gau_sigma, double *__restrict__ sim_out, double *__restrict__ like_out) {
+    extern __shared__ double smem[];
+    double *Mloc = smem;                          // [n][SPB]
+    double *part = Mloc + (size_t)n * SPB;        // [4 waves][SPB][7]
+    double *mom = part + 4 * SPB * 7;             // [k][SPB][NMOM]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * SPB;
+
+    for (int i = tid; i < n * SPB; i += MC_THREADS) {
+        const int j = i / SPB, s = i % SPB;
+        Mloc[i] = (s0 + s < nsamp) ? Ms[(int64_t)j * nsamp + s0 + s] : 0.0;  // reference layout MTs[:, i]
+    }
+    __syncthreads();
+
+    for (int kk = 0; kk < k; ++kk) {
+        double a1[SPB], a2[SPB], ads[SPB], amx[SPB], ass1[SPB], ads1[SPB], ad1s[SPB];
+#pragma unroll
+        for (int s = 0; s < SPB; ++s) a1[s] = a2[s] = ads[s] = amx[s] = ass1[s] = ads1[s] = ad1s[s] = 0.0;
+        const double *Gk = G + (int64_t)kk * n * t;
+        const double *dk = d + (int64_t)kk * t;
+        for (int e = tid; e < t; e += MC_THREADS) {
+            double sv[SPB], sn[SPB];
+#pragma unroll
+            for (int s = 0; s < SPB; ++s) sv[s] = sn[s] = 0.0;
+            const bool has_next = LAG && (e + 1 < t);
+            for (int j = 0; j < n; ++j) {  // same j order as the reference's accumulation
+                const double g = Gk[(int64_t)j * t + e];
+                const double gn = has_next ? Gk[(int64_t)j * t + e + 1] : 0.0;
+#pragma unroll
+                for (int s = 0; s < SPB; ++s) {
+                    sv[s] += g * Mloc[j * SPB + s];
+                    if (LAG) sn[s] += gn * Mloc[j * SPB + s];
+                }
+            }
+            const double dv = dk[e];
+            const double dn = has_next ? dk[e + 1] : 0.0;
+#pragma unroll
+            for (int s = 0; s < SPB; ++s) {
+                a1[s] += sv[s];
+                a2[s] += sv[s] * sv[s];
+                ads[s] += dv * sv[s];
+                amx[s] = fmax(amx[s], fabs(sv[s]));
+                if (LAG && has_next) {
+                    ass1[s] += sv[s] * sn[s];
+                    ads1[s] += dv * sn[s];
+                    ad1s[s] += dn * sv[s];
+                }
+                if (e == 0) mom[((size_t)kk * SPB + s) * NMOM + M_FIRST] = sv[s];
+                if (e == t - 1) mom[((size_t)kk * SPB + s) * NMOM + M_LAST] = sv[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SPB; ++s) {
+            const double r1 = wave_sum(a1[s]), r2 = wave_sum(a2[s]), r3 = wave_sum(ads[s]), r4 = wave_max(amx[s]);
+            double r5 = 0.0, r6 = 0.0, r7 = 0.0;
+            if (LAG) {
+                r5 = wave_sum(ass1[s]);
+                r6 = wave_sum(ads1[s]);
+                r7 = wave_sum(ad1s[s]);
+            }
+            if (lane == 0) {
+                double *p = part + ((size_t)wave * SPB + s) * 7;
+                p[0] = r1; p[1] = r2; p[2] = r3; p[3] = r4; p[4] = r5; p[5] = r6; p[6] = r7;
+            }
+        }
+        __syncthreads();
+        if (tid < SPB * 7) {
+            const int s = tid / 7, m = tid % 7;
+            double v = part[((size_t)0 * SPB + s) * 7 + m];
+            for (int w = 1; w < 4; ++w) {
+                const double o = part[((size_t)w * SPB + s) * 7 + m];
+                v = (m == M_MAX) ? fmax(v, o) : v + o;
+            }
+            mom[((size_t)kk * SPB + s) * NMOM + m] = v;
+        }
+        __syncthreads();
+    }
+
+    // one thread per sample turns the moments into the similarity value
+    if (tid < SPB && s0 + tid < nsamp) {
+        const int s = tid;
+        const double L = (double)t;
+        double acc = 0.0;                    // per-trace mode: sum of per-trace similarities
+        double num = 0.0, den = 0.0;         // all-at-once VR / gau sums
+        SeqMom tot = {0, 0, 0, 0, 0, 0};     // all-at-once correlation moments
+        double prev_dl = 0.0, prev_sl = 0.0; // last normalised values of the previous trace (flattened lag)
+        for (int kk = 0; kk < k; ++kk) {
+            const double *m = mom + ((size_t)kk * SPB + s) * NMOM;
+            const double *dm = dmom + (size_t)kk * NDMOM;
+            const double a = normalise ? 1.0 / dm[D_MAX] : 1.0;
+            const double b = normalise ? 1.0 / m[M_MAX] : 1.0;
+            const double dd = a * a * dm[D_2], ss = b * b * m[M_S2], ds = a * b * m[M_DS];
+            const double d1 = a * dm[D_1], s1 = b * m[M_S1];
+            const double res = dd - 2.0 * ds + ss;  // sum (d' - s')^2
+            if (metric == MC_VR) {
+                if (all_at_once) { num += res; den += dd; }
+                else { const double vr = 1.0 - res / dd; acc += vr < 0.0 ? 0.0 : vr; }
+            } else if (metric == MC_GAU) {
+                num += res;  // per-trace 'gau' returns 0 in the reference (quirk), handled below
+            } else if (metric == MC_CC || metric == MC_PCC) {
+                if (all_at_once) { tot.sx += d1; tot.sy += s1; tot.sxx += dd; tot.syy += ss; tot.sxy += ds; tot.len += L; }
+                else { SeqMom q = {d1, s1, dd, ss, ds, L}; acc += corr_from(q); }
+            } else {  // MC_CCSHIFT: moments of the 4x interpolated sequences
+                const double df = a * dm[D_FIRST], dl = a * dm[D_LAST], sf = b * m[M_FIRST], sl = b * m[M_LAST];
+                const double dd1 = a * a * dm[D_DD1], ss1 = b * b * m[M_SS1];
+                const double ds1 = a * b * m[M_DS1], d1s = a * b * m[M_D1S];
+                if (!all_at_once) {
+                    SeqMom q;
+                    q.len = 4.0 * L;
+                    q.sx = up_sum(d1, df, dl);
+                    q.sy = up_sum(s1, sf, sl);
+                    q.sxx = up_dot(dd, dd1, dd1, df * df, dl * dl);
+                    q.syy = up_dot(ss, ss1, ss1, sf * sf, sl * sl);
+                    q.sxy = up_dot(ds, ds1, d1s, df * sf, dl * sl);
+                    acc += corr_from(q);
+                } else {
+                    // flattened sequence: plain sums now, lag-1 products get the trace-boundary terms;
+                    // the first/last corrections are applied once, after the loop
+                    tot.sx += d1; tot.sy += s1; tot.sxx += dd; tot.syy += ss; tot.sxy += ds; tot.len += L;
+                    num += dd1 + (kk ? prev_dl * df : 0.0);        // sum x_i x_{i+1}   (data)
+                    den += ss1 + (kk ? prev_sl * sf : 0.0);        // sum y_i y_{i+1}   (synth)
+                    acc += ds1 + d1s + (kk ? prev_dl * sf + prev_sl * df : 0.0);  // x_i y_{i+1} + x_{i+1} y_i
+                    prev_dl = dl; prev_sl = sl;
+                }
+            }
+        }
+        double sim;
+        if (metric == MC_VR) {
+            if (all_at_once) { sim = 1.0 - num / den; sim = sim < 0.0 ? 0.0 : sim; }
+            else sim = acc / k;
+        } else if (metric == MC_GAU) {
+            sim = all_at_once ? exp(-num / (2.0 * gau_sigma * gau_sigma)) : 0.0;
+        } else if (metric == MC_CC || metric == MC_PCC) {
+            sim = all_at_once ? corr_from(tot) : acc / k;
+        } else if (!all_at_once) {
+            sim = acc / k;
+        } else {
+            const double *m0 = mom + ((size_t)0 * SPB + s) * NMOM, *mL = mom + ((size_t)(k - 1) * SPB + s) * NMOM;
+            const double a0 = normalise ? 1.0 / dmom[D_MAX] : 1.0, b0 = normalise ? 1.0 / m0[M_MAX] : 1.0;
+            const double aL = normalise ? 1.0 / dmom[(size_t)(k - 1) * NDMOM + D_MAX] : 1.0;
+            const double bL = normalise ? 1.0 / mL[M_MAX] : 1.0;
+            const double df = a0 * dmom[D_FIRST], sf = b0 * m0[M_FIRST];
+            const double dl = aL * dmom[(size_t)(k - 1) * NDMOM + D_LAST], sl = bL * mL[M_LAST];
+            SeqMom q;
+            q.len = 4.0 * tot.len;
+            q.sx = up_sum(tot.sx, df, dl);
+            q.sy = up_sum(tot.sy, sf, sl);
+            q.sxx = up_dot(tot.sxx, num, num, df * df, dl * dl);
+            q.syy = up_dot(tot.syy, den, den, sf * sf, sl * sl);
+            q.sxy = 1.875 * (tot.sxy - dl * sl) + 0.875 * (tot.sxy - df * sf) + 0.625 * acc + 4.0 * dl * sl;
+            sim = corr_from(q);
+        }
+        sim_out[s0 + s] = sim;
+        if (like_out) like_out[s0 + s] = exp(-(1.0 - sim) / 2.0);  // :774
+    }
+}
+
+// forward_model for a batch: synth[i, k, t] (full_waveform_inversion.py:253-264), same j order
+__global__ void mc_forward_kernel(const double *__restrict__ G, const double *__restrict__ Ms, int k, int n,
+                                  int t, int64_t nsamp, double *__restrict__ synth) {
+    const int64_t kt = (int64_t)k * t;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nsamp * kt;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / kt, r = i - s * kt;
+        const int kk = (int)(r / t), e = (int)(r % t);
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) v += G[((int64_t)kk * n + j) * t + e] * Ms[(int64_t)j * nsamp + s];
+        synth[i] = v;
+    }
+}
+
+hipError_t launch_mc_score(const double *G, const double *d, const double *Ms, const double *dmom, int k, int n,
+                           int t, int64_t nsamp, int metric, int normalise, int all_at_once, double gau_sigma,
+                           double *sim, double *like, hipStream_t s) {
+    const size_t shm = ((size_t)n * SPB + 4 * SPB * 7 + (size_t)k * SPB * NMOM) * sizeof(double);
+    const unsigned grid = (unsigned)((nsamp + SPB - 1) / SPB);
+    if (metric == MC_CCSHIFT)
+        hipLaunchKernelGGL(mc_score_kernel<true>, dim3(grid), dim3(MC_THREADS), shm, s, G, d, Ms, dmom, k, n, t,
+                           nsamp, metric, normalise, all_at_once, gau_sigma, sim, like);
+    else
+        hipLaunchKernelGGL(mc_score_kernel<false>, dim3(grid), dim3(MC_THREADS), shm, s, G, d, Ms, dmom, k, n, t,
+                           nsamp, metric, normalise, all_at_once, gau_sigma, sim, like);
+    return hipGetLastError();
+}
+
+hipError_t launch_mc_forward(const double *G, const double *Ms, int k, int n, int t, int64_t nsamp, double *synth,
+                             hipStream_t s) {
+    const int64_t tot = nsamp * k * t;
+    const unsigned grid = (unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(mc_forward_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, G, Ms, k, n, t, nsamp, synth);
+    return hipGetLastError();
+}
+
+size_t mc_score_lds_bytes(int k, int n) {
+    return ((size_t)n * SPB + 4 * SPB * 7 + (size_t)k * SPB * NMOM) * sizeof(double);
+}
+
+}  // namespace fwi

@@ -1,0 +1,118 @@
+"""GPU drop-in for the reference's REAL hot loop.
+
+Mirrors the reference's function names and argument meaning for the source-inversion path:
+``forward_model(green_func_array, M)`` (full_waveform_inversion.py:253),
+``compare_synth_to_real_waveforms(...)`` (:584) and the scoring part of
+``perform_monte_carlo_sampled_waveform_inversion`` (:786).  The per-sample loop body
+(forward model + similarity + likelihood, :713-774) runs as one fused HIP kernel over all
+samples; the random source samplers (:282-510) are left to the caller (simple full-MT and
+single-force samplers are provided for convenience, using numpy's Generator, so their
+streams differ from the reference's unseeded global RNGs).  fp64 like the reference.
+There is no CPU fallback: without the HIP library / a GPU these raise FwiError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def forward_model_batch(green_func_array, MTs, device=0):
+    """Synthetics for every column of ``MTs (n, N)``: array ``(N, k, t)``."""
+    G = _f64(green_func_array)
+    M = _f64(MTs)
+    if G.ndim != 3 or M.ndim != 2 or M.shape[0] != G.shape[1]:
+        raise ValueError("green_func_array must be (k, n, t) and MTs (n, N)")
+    k, n, t = G.shape
+    out = np.empty((M.shape[1], k, t))
+    _lib.check(None, _lib.load().fwi_mc_forward(device, k, n, t, M.shape[1], _p(G), _p(M), _p(out)))
+    return out
+
+
+def forward_model(green_func_array, M, device=0):
+    """``synth[k, t] = sum_j G[k, j, t] * M[j]`` -- same contract as the reference's function."""
+    M = _f64(M).reshape(-1, 1)
+    return forward_model_batch(green_func_array, M, device)[0]
+
+
+def score_samples(real_data_array, green_func_array, MTs, comparison_metric="VR",
+                  perform_normallised_waveform_inversion=True, compare_all_waveforms_simultaneously=True,
+                  device=0, return_timing=False):
+    """Similarity of every sample's synthetic to the data: the reference's steps 4-5 for given samples.
+
+    Returns ``(similarity (N,), likelihood (N,), posterior (N,))`` [+ kernel milliseconds].
+    """
+    G, d, M = _f64(green_func_array), _f64(real_data_array), _f64(MTs)
+    if G.ndim != 3 or d.shape != (G.shape[0], G.shape[2]) or M.ndim != 2 or M.shape[0] != G.shape[1]:
+        raise ValueError("shapes must be G (k, n, t), data (k, t), MTs (n, N)")
+    if comparison_metric not in _lib.MC_METRICS:
+        raise ValueError("comparison_metric must be one of %s" % sorted(_lib.MC_METRICS))
+    k, n, t = G.shape
+    N = M.shape[1]
+    sim, like, post = np.empty(N), np.empty(N), np.empty(N)
+    ms = C.c_double(0.0)
+    _lib.check(None, _lib.load().fwi_mc_score(
+        device, k, n, t, N, _p(G), _p(d), _p(M), _lib.MC_METRICS[comparison_metric],
+        int(bool(perform_normallised_waveform_inversion)), int(bool(compare_all_waveforms_simultaneously)),
+        _p(sim), _p(like), _p(post), C.byref(ms)))
+    return (sim, like, post, ms.value) if return_timing else (sim, like, post)
+
+
+def compare_synth_to_real_waveforms(real_data_array, green_func_array, M, comparison_metric,
+                                    perform_normallised_waveform_inversion=True,
+                                    compare_all_waveforms_simultaneously=True, device=0):
+    """Similarity for ONE source vector.  Differs from the reference's signature in taking the
+    Green's functions and the source instead of a precomputed synthetic: the synthetic never
+    leaves the GPU."""
+    return float(score_samples(real_data_array, green_func_array, _f64(M).reshape(-1, 1), comparison_metric,
+                               perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously,
+                               device)[0][0])
+
+
+def random_full_mt(num_samples, rng):
+    """Unit 6-vectors uniform on the 5-sphere (what generate_random_MT, :282-293, produces)."""
+    v = rng.standard_normal((6, num_samples))
+    return v / np.linalg.norm(v, axis=0, keepdims=True)
+
+
+def random_single_force(num_samples, rng):
+    """Unit 3-vectors uniform on the sphere (generate_random_single_force_vector, :320-331)."""
+    v = rng.standard_normal((3, num_samples))
+    return v / np.linalg.norm(v, axis=0, keepdims=True)
+
+
+def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_array, num_samples=1000,
+                                                   M_amplitude=1.0, inversion_type="full_mt",
+                                                   comparison_metric="CC",
+                                                   perform_normallised_waveform_inversion=True,
+                                                   compare_all_waveforms_simultaneously=True, MTs=None,
+                                                   seed=0, device=0):
+    """The reference's driver (:786-870) with the sample loop on the GPU.
+
+    ``MTs (n, N)`` may be supplied (e.g. drawn by the reference's own samplers); otherwise
+    ``full_mt`` / ``single_force`` samples are drawn here.  Returns ``(MTs, MTp, MTp_absolute)``
+    like the reference: samples, posterior ``L / sum L`` and the likelihoods ``exp(-(1-s)/2)``.
+    """
+    if MTs is None:
+        rng = np.random.default_rng(seed)
+        if inversion_type == "full_mt":
+            MTs = random_full_mt(num_samples, rng) * M_amplitude
+        elif inversion_type == "single_force":
+            MTs = random_single_force(num_samples, rng) * M_amplitude
+        else:
+            raise ValueError("built-in samplers cover 'full_mt' and 'single_force'; pass MTs for %r"
+                             % inversion_type)
+    _, like, post = score_samples(real_data_array, green_func_array, MTs, comparison_metric,
+                                  perform_normallised_waveform_inversion,
+                                  compare_all_waveforms_simultaneously, device)
+    return np.asarray(MTs, float), post, like

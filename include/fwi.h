@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 1
+#define FWI_ABI_VERSION 2
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -136,6 +136,29 @@ int fwi_synchronize(fwi_ctx *ctx);
 const char *fwi_kernel_name(const fwi_ctx *ctx);
 /* Device count / name without creating a context (returns FWI_EHIP if none). */
 int fwi_device_count(int32_t *n_out);
+
+/* ---------------------------------------------------------------------------
+ * the reference's REAL hot loop, batched over N source samples.
+ * Steps 4-7 of PARALLEL_worker_mc_inv (full_waveform_inversion.py:713-774) for
+ * given samples: forward_model (:253-264), compare_synth_to_real_waveforms
+ * (:584-684) with one of the five similarity metrics (:512-582), the likelihood
+ * map exp(-(1-s)/2) (:774) and the posterior normalisation (:847-848).  fp64 like
+ * the reference; the random samplers (:282-510) stay with the caller.
+ *   green   (k, n, t)   Green's functions        data (k, t)   observed traces
+ *   samples (n, nsamp)  source vectors, the reference's MTs[:, i] layout
+ * Stateless: buffers are uploaded, scored and freed inside the call.
+ * ------------------------------------------------------------------------- */
+enum { FWI_MC_VR = 0, FWI_MC_CC = 1, FWI_MC_PCC = 2, FWI_MC_CCSHIFT = 3, FWI_MC_GAU = 4 };
+
+int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
+                 const double *data, const double *samples, int32_t metric, int32_t normalise,
+                 int32_t all_at_once, double *similarity_out /* nsamp */,
+                 double *likelihood_out /* nsamp or NULL */, double *posterior_out /* nsamp or NULL */,
+                 double *kernel_ms_out /* or NULL */);
+
+/* forward_model for a batch: synth_out (nsamp, k, t).  [full_waveform_inversion.py:253-264] */
+int fwi_mc_forward(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
+                   const double *samples, double *synth_out);
 
 #ifdef __cplusplus
 }

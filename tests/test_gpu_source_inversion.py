@@ -1,0 +1,97 @@
+"""GPU parity of the reference's REAL hot loop (SURVEY s.8f-2) -- PINNED to reference code.
+
+Golden vectors in tests/golden/ref_mc_*.npz were produced by the reference's own functions
+(tests/golden/make_reference_golden.py); the GPU path must reproduce them, and the pinned
+oracle (oracle/mc_oracle.py) on fresh seeded inputs incl. the reference's shipped shape
+(k = 21 traces, n = 9 components)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import FwiError, source_inversion as si
+from oracle import mc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["ref_mc_fullmt", "ref_mc_force", "ref_mc_dc"]
+METRICS = ["VR", "CC", "PCC", "CC-shift", "gau"]
+TOL = 1e-9  # fp64 both sides; moments vs direct sums differ by round-off only
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_model_vs_reference_golden(gpu, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = si.forward_model_batch(z["G"], z["M"])
+    assert np.allclose(got, z["synth"], rtol=1e-13, atol=1e-14 * np.abs(z["synth"]).max())
+    one = si.forward_model(z["G"], z["M"][:, 3:4])
+    assert np.allclose(one, z["synth"][3], rtol=1e-13, atol=1e-14 * np.abs(z["synth"]).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("allat", [False, True])
+def test_similarity_vs_reference_golden(gpu, name, metric, norm, allat):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    ref = z["sim_%s_n%d_a%d" % (metric.replace("-", ""), norm, allat)]
+    sim, like, post = si.score_samples(z["d"], z["G"], z["M"], metric, norm, allat)
+    assert np.allclose(sim, ref, rtol=TOL, atol=1e-12), np.abs(sim - ref).max()
+    assert np.allclose(like, np.exp(-(1.0 - ref) / 2.0), rtol=TOL)
+    assert abs(post.sum() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_driver_vs_reference_golden(gpu, name):
+    """Posterior and likelihoods of the reference's own driver run (one process, seeded)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    MTs, MTp, MTp_abs = si.perform_monte_carlo_sampled_waveform_inversion(
+        z["d"], z["G"], comparison_metric="VR", perform_normallised_waveform_inversion=False,
+        compare_all_waveforms_simultaneously=False, MTs=z["drv_MTs"])
+    assert np.allclose(MTp_abs, z["drv_MTp_absolute"], rtol=TOL)
+    assert np.allclose(MTp, z["drv_MTp"], rtol=TOL)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_shipped_shape_vs_pinned_oracle(gpu, metric):
+    """k = 21, n = 9, t = 512 (the reference's shipped configuration), 37 samples (ragged batch)."""
+    rng = np.random.default_rng(3)
+    k, n, t, N = 21, 9, 512, 37
+    G = np.cumsum(rng.standard_normal((k, n, t)), axis=2) * np.hanning(t)
+    Mt = rng.standard_normal(n)
+    d = np.einsum("kjt,j->kt", G, Mt) + 0.1 * G.std() * rng.standard_normal((k, t))
+    Ms = np.concatenate([rng.standard_normal((n, N - 1)), Mt[:, None]], axis=1)
+    for norm in (False, True):
+        for allat in (False, True):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.array([mo.compare_synth_to_real_waveforms(d, mo.forward_model(G, Ms[:, i]), metric,
+                                                                   norm, allat) for i in range(N)])
+            sim = si.score_samples(d, G, Ms, metric, norm, allat)[0]
+            assert np.allclose(sim, ref, rtol=TOL, atol=1e-12), (norm, allat, np.abs(sim - ref).max())
+
+
+def test_million_samples_best_is_truth(gpu):
+    """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
+    rng = np.random.default_rng(0)
+    k, n, t, N = 21, 6, 256, 1 << 20
+    G = rng.standard_normal((k, n, t))
+    Mt = si.random_full_mt(1, rng)
+    d = np.einsum("kjt,j->kt", G, Mt[:, 0])
+    Ms = si.random_full_mt(N, rng)
+    Ms[:, 12345] = Mt[:, 0]
+    sim, like, post, ms = si.score_samples(d, G, Ms, "VR", False, False, return_timing=True)
+    assert np.argmax(sim) == 12345 and abs(sim[12345] - 1.0) < 1e-12
+    assert abs(post.sum() - 1.0) < 1e-9 and np.argmax(post) == 12345
+    assert N / (ms * 1e-3) > 1e6  # the reference manages ~1e3 samples/s per core
+
+
+def test_errors(gpu):
+    G, d = np.ones((2, 3, 8)), np.ones((2, 8))
+    with pytest.raises(ValueError):
+        si.score_samples(d, G, np.ones((4, 5)))
+    with pytest.raises(ValueError):
+        si.score_samples(d, G, np.ones((3, 5)), "nope")
+    with pytest.raises(FwiError):
+        si.score_samples(d, G, np.ones((3, 5)), device=99)
