@@ -18,7 +18,7 @@
 
 namespace fwi {
 
-constexpr int SPB = 4;        // samples per workgroup
+constexpr int SPB = 8;        // samples per workgroup (G is re-read once per workgroup)
 constexpr int MC_THREADS = 256;
 // moments per (sample, trace)
 enum { M_S1 = 0, M_S2, M_DS, M_MAX, M_SS1, M_DS1, M_D1S, M_FIRST, M_LAST, NMOM };
@@ -58,15 +58,16 @@ __device__ __forceinline__ double up_dot(double p0, double p1, double p1r, doubl
     return 1.875 * (p0 - xLyL) + 0.875 * (p0 - x0y0) + 0.625 * (p1 + p1r) + 4.0 * xLyL;
 }
 
-template <bool LAG>
+// NC = number of source components when it is one of the reference's 3 / 6 / 9 (the component loop is
+// then unrolled with all G loads of a time sample in flight at once), 0 = any n (rolled loop).
+template <bool LAG, int NC>
 __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
     const double *__restrict__ G, const double *__restrict__ d, const double *__restrict__ Ms,
     const double *__restrict__ dmom, int k, int n, int t, int64_t nsamp, int metric, int normalise,
     int all_at_once, double gau_sigma, double *__restrict__ sim_out, double *__restrict__ like_out) {
     extern __shared__ double smem[];
     double *Mloc = smem;                          // [n][SPB]
-    double *part = Mloc + (size_t)n * SPB;        // [4 waves][SPB][7]
-    double *mom = part + 4 * SPB * 7;             // [k][SPB][NMOM]
+    double *mom = Mloc + (size_t)n * SPB;         // [k][SPB][NMOM]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t s0 = (int64_t)blockIdx.x * SPB;
 
@@ -76,24 +77,44 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
     }
     __syncthreads();
 
-    for (int kk = 0; kk < k; ++kk) {
+    // Each wave owns whole traces (kk = wave, wave + 4, ...): lanes stream consecutive time samples
+    // (coalesced), keep per-lane partial moments, and one shuffle reduction per trace yields the
+    // moments -- no workgroup barrier inside the trace loop.
+    for (int kk = wave; kk < k; kk += MC_THREADS / 64) {
         double a1[SPB], a2[SPB], ads[SPB], amx[SPB], ass1[SPB], ads1[SPB], ad1s[SPB];
 #pragma unroll
         for (int s = 0; s < SPB; ++s) a1[s] = a2[s] = ads[s] = amx[s] = ass1[s] = ads1[s] = ad1s[s] = 0.0;
         const double *Gk = G + (int64_t)kk * n * t;
         const double *dk = d + (int64_t)kk * t;
-        for (int e = tid; e < t; e += MC_THREADS) {
+        for (int e = lane; e < t; e += 64) {
             double sv[SPB], sn[SPB];
 #pragma unroll
             for (int s = 0; s < SPB; ++s) sv[s] = sn[s] = 0.0;
             const bool has_next = LAG && (e + 1 < t);
-            for (int j = 0; j < n; ++j) {  // same j order as the reference's accumulation
-                const double g = Gk[(int64_t)j * t + e];
-                const double gn = has_next ? Gk[(int64_t)j * t + e + 1] : 0.0;
+            if (NC > 0) {
+                double g[NC > 0 ? NC : 1], gn[NC > 0 ? NC : 1];
 #pragma unroll
-                for (int s = 0; s < SPB; ++s) {
-                    sv[s] += g * Mloc[j * SPB + s];
-                    if (LAG) sn[s] += gn * Mloc[j * SPB + s];
+                for (int j = 0; j < NC; ++j) {
+                    g[j] = Gk[(int64_t)j * t + e];
+                    gn[j] = has_next ? Gk[(int64_t)j * t + e + 1] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {  // same j order as the reference's accumulation
+#pragma unroll
+                    for (int s = 0; s < SPB; ++s) {
+                        sv[s] += g[j] * Mloc[j * SPB + s];
+                        if (LAG) sn[s] += gn[j] * Mloc[j * SPB + s];
+                    }
+                }
+            } else {
+                for (int j = 0; j < n; ++j) {
+                    const double g = Gk[(int64_t)j * t + e];
+                    const double gn = has_next ? Gk[(int64_t)j * t + e + 1] : 0.0;
+#pragma unroll
+                    for (int s = 0; s < SPB; ++s) {
+                        sv[s] += g * Mloc[j * SPB + s];
+                        if (LAG) sn[s] += gn * Mloc[j * SPB + s];
+                    }
                 }
             }
             const double dv = dk[e];
@@ -123,22 +144,12 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
                 r7 = wave_sum(ad1s[s]);
             }
             if (lane == 0) {
-                double *p = part + ((size_t)wave * SPB + s) * 7;
-                p[0] = r1; p[1] = r2; p[2] = r3; p[3] = r4; p[4] = r5; p[5] = r6; p[6] = r7;
+                double *p = mom + ((size_t)kk * SPB + s) * NMOM;
+                p[M_S1] = r1; p[M_S2] = r2; p[M_DS] = r3; p[M_MAX] = r4; p[M_SS1] = r5; p[M_DS1] = r6; p[M_D1S] = r7;
             }
         }
-        __syncthreads();
-        if (tid < SPB * 7) {
-            const int s = tid / 7, m = tid % 7;
-            double v = part[((size_t)0 * SPB + s) * 7 + m];
-            for (int w = 1; w < 4; ++w) {
-                const double o = part[((size_t)w * SPB + s) * 7 + m];
-                v = (m == M_MAX) ? fmax(v, o) : v + o;
-            }
-            mom[((size_t)kk * SPB + s) * NMOM + m] = v;
-        }
-        __syncthreads();
     }
+    __syncthreads();
 
     // one thread per sample turns the moments into the similarity value
     if (tid < SPB && s0 + tid < nsamp) {
@@ -236,14 +247,19 @@ __global__ void mc_forward_kernel(const double *__restrict__ G, const double *__
 hipError_t launch_mc_score(const double *G, const double *d, const double *Ms, const double *dmom, int k, int n,
                            int t, int64_t nsamp, int metric, int normalise, int all_at_once, double gau_sigma,
                            double *sim, double *like, hipStream_t s) {
-    const size_t shm = ((size_t)n * SPB + 4 * SPB * 7 + (size_t)k * SPB * NMOM) * sizeof(double);
+    const size_t shm = ((size_t)n * SPB + (size_t)k * SPB * NMOM) * sizeof(double);
     const unsigned grid = (unsigned)((nsamp + SPB - 1) / SPB);
-    if (metric == MC_CCSHIFT)
-        hipLaunchKernelGGL(mc_score_kernel<true>, dim3(grid), dim3(MC_THREADS), shm, s, G, d, Ms, dmom, k, n, t,
-                           nsamp, metric, normalise, all_at_once, gau_sigma, sim, like);
-    else
-        hipLaunchKernelGGL(mc_score_kernel<false>, dim3(grid), dim3(MC_THREADS), shm, s, G, d, Ms, dmom, k, n, t,
-                           nsamp, metric, normalise, all_at_once, gau_sigma, sim, like);
+#define MC_LAUNCH(LAG, NC)                                                                                  \
+    hipLaunchKernelGGL((mc_score_kernel<LAG, NC>), dim3(grid), dim3(MC_THREADS), shm, s, G, d, Ms, dmom, k, n, \
+                       t, nsamp, metric, normalise, all_at_once, gau_sigma, sim, like)
+    const bool lag = metric == MC_CCSHIFT;
+    switch (n) {
+        case 3: if (lag) MC_LAUNCH(true, 3); else MC_LAUNCH(false, 3); break;
+        case 6: if (lag) MC_LAUNCH(true, 6); else MC_LAUNCH(false, 6); break;
+        case 9: if (lag) MC_LAUNCH(true, 9); else MC_LAUNCH(false, 9); break;
+        default: if (lag) MC_LAUNCH(true, 0); else MC_LAUNCH(false, 0); break;
+    }
+#undef MC_LAUNCH
     return hipGetLastError();
 }
 
@@ -256,7 +272,7 @@ hipError_t launch_mc_forward(const double *G, const double *Ms, int k, int n, in
 }
 
 size_t mc_score_lds_bytes(int k, int n) {
-    return ((size_t)n * SPB + 4 * SPB * 7 + (size_t)k * SPB * NMOM) * sizeof(double);
+    return ((size_t)n * SPB + (size_t)k * SPB * NMOM) * sizeof(double);
 }
 
 }  // namespace fwi
