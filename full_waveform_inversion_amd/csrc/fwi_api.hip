@@ -74,8 +74,14 @@ struct fwi_ctx {
              *s_col = nullptr;
         size_t cap = 0, cap_start = 0;
     } src, rec;
-    void *amp = nullptr, *series = nullptr;  // (nt, ninj) injected / (nt, nrec) recorded
-    size_t cap_amp = 0, cap_series = 0;
+    void *wav = nullptr;     // (nt, nsrc) source wavelets of the last forward (kept for recomputation)
+    void *amp = nullptr;     // (nt, nrec) residual being back-propagated
+    void *series = nullptr;  // (nt, n) sampled series of the running sweep
+    size_t cap_wav = 0, cap_amp = 0, cap_series = 0;
+    // checkpointing (SURVEY s.8f-3): snapshot of (u^n, u^{n-1}) every `ckpt` steps instead of the
+    // imaging term of every step; q_store then holds ckpt + 1 slots and fwd[] the recomputed fields
+    int ckpt = 0;
+    void *snap = nullptr, *fwd[2] = {nullptr, nullptr};
 
     ncclComm_t comm = nullptr;
     int nranks = 1;
@@ -298,56 +304,63 @@ struct Impl {
         return upload_set(ctx, ctx->rec, nrec, rec_idx, 1.0);
     }
 
-    // The shared time loop (oracle: Propagator._propagate): inject `amp` rows at point set
-    // `inj`, sample the new field at point set `out` into `series`.
-    static int propagate(fwi_ctx *ctx, bool reverse, const fwi_ctx::PointSet &inj,
-                         const fwi_ctx::PointSet &out, T out_scale, bool save_q, bool image) {
+    // State of one field pair being stepped: which buffer holds the newest field, and the step
+    // whose sampling is still owed (it rides on the next launch).
+    struct Sweep {
+        void *f[2];
+        int cur = 0;
+        int prev_n = -1;
+    };
+
+    // Steps n = n0, n0 + dn, ... (count steps) of the shared time loop (oracle:
+    // Propagator._propagate): inject `amp` rows at point set `inj`, sample the new field at point
+    // set `out` (nullptr = none) into `series`; q_out(n) / q_in(n) give the per-step imaging-term
+    // pointers (nullptr = off).  Injection and sampling are fused into the step launch: one launch
+    // per time step; the sampling of step n rides on the next launch, which reads that field anyway.
+    template <class QOut, class QIn>
+    static int run_steps(fwi_ctx *ctx, Sweep &sw, int n0, int dn, int count, const fwi_ctx::PointSet &inj,
+                         const T *amp, const fwi_ctx::PointSet *out, T *series, T out_scale, QOut q_out,
+                         QIn q_in) {
         const GridDesc &g = ctx->gd;
-        const int nt = ctx->nt;
-        hipStream_t s = ctx->stream;
-        HIPCHK(ctx, hipMemsetAsync(ctx->u[0], 0, (size_t)g.ptot * sizeof(T), s));
-        HIPCHK(ctx, hipMemsetAsync(ctx->u[1], 0, (size_t)g.ptot * sizeof(T), s));
-        T *q_store = (T *)ctx->q_store;
-        T *series = (T *)ctx->series;
-        const T *amp = (const T *)ctx->amp;
-        // Injection and sampling are fused into the step launch: one launch per time step.
-        // The sampling of step n rides on launch n+1, which reads that field anyway.
-        int cur = 0, prev_n = -1;
-        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
-        for (int it = 0; it < nt; ++it) {
-            const int n = reverse ? nt - 1 - it : it;
-            StepArgs<T> a = base_args(ctx, cur);
-            if (save_q) a.q_out = q_store + (size_t)n * g.npts;
-            // lagged imaging: u_cur of adjoint step n is mu^{n+2}, which pairs with q^{n+1}
-            if (image && n + 1 < nt) a.q_in = q_store + (size_t)(n + 1) * g.npts;
-            {
-                if (inj.n > 0) {
-                    a.inj_start = (const int *)inj.s_start;
-                    a.inj_pidx = (const int64_t *)inj.s_pidx;
-                    a.inj_cidx = (const int64_t *)inj.s_cidx;
-                    a.inj_cu = (const T *)inj.s_cu;
-                    a.inj_cq = (const T *)inj.s_cq;
-                    a.inj_col = (const int *)inj.s_col;
-                    a.inj_amp = amp + (size_t)n * inj.n;
-                }
-                if (prev_n >= 0 && out.n > 0) {
-                    a.rec_pidx = (const int64_t *)out.pidx;
-                    a.rec_out = series + (size_t)prev_n * out.n;
-                    a.rec_scale = out_scale;
-                    a.nrec = out.n;
-                }
+        for (int it = 0, n = n0; it < count; ++it, n += dn) {
+            StepArgs<T> a = base_args(ctx, 0);
+            a.u_cur = (const T *)sw.f[sw.cur];
+            a.u_prev = (T *)sw.f[sw.cur ^ 1];
+            a.q_out = q_out(n);
+            a.q_in = q_in(n);
+            if (inj.n > 0) {
+                a.inj_start = (const int *)inj.s_start;
+                a.inj_pidx = (const int64_t *)inj.s_pidx;
+                a.inj_cidx = (const int64_t *)inj.s_cidx;
+                a.inj_cu = (const T *)inj.s_cu;
+                a.inj_cq = (const T *)inj.s_cq;
+                a.inj_col = (const int *)inj.s_col;
+                a.inj_amp = amp + (size_t)n * inj.n;
             }
-            HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, s));
-            prev_n = n;
-            cur ^= 1;
+            if (out && sw.prev_n >= 0 && out->n > 0) {
+                a.rec_pidx = (const int64_t *)out->pidx;
+                a.rec_out = series + (size_t)sw.prev_n * out->n;
+                a.rec_scale = out_scale;
+                a.nrec = out->n;
+            }
+            HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
+            sw.prev_n = n;
+            sw.cur ^= 1;
         }
-        // the last step's field has no following launch to ride on
-        HIPCHK(ctx, launch_record<T>((const T *)ctx->u[cur], (const int64_t *)out.pidx,
-                                         series + (size_t)prev_n * out.n, out_scale, out.n, s));
-        if (image)  // the last pairing: mu^1 with q^0
-            HIPCHK(ctx, launch_image<T>(g, (const T *)ctx->u[cur], q_store, (T *)ctx->g_acc, s));
-        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
-        ctx->have_loop_time = true;
+        return FWI_OK;
+    }
+
+    // the last step's field has no following launch to ride on
+    static int flush_record(fwi_ctx *ctx, Sweep &sw, const fwi_ctx::PointSet &out, T *series, T out_scale) {
+        if (sw.prev_n < 0) return FWI_OK;
+        HIPCHK(ctx, launch_record<T>((const T *)sw.f[sw.cur], (const int64_t *)out.pidx,
+                                     series + (size_t)sw.prev_n * out.n, out_scale, out.n, ctx->stream));
+        return FWI_OK;
+    }
+
+    static int zero_fields(fwi_ctx *ctx, void *a, void *b) {
+        HIPCHK(ctx, hipMemsetAsync(a, 0, (size_t)ctx->gd.ptot * sizeof(T), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b, 0, (size_t)ctx->gd.ptot * sizeof(T), ctx->stream));
         return FWI_OK;
     }
 
@@ -355,38 +368,70 @@ struct Impl {
                        const T *wavelet, int32_t nrec, const int32_t *rec_idx, int32_t save,
                        T *seis_out) {
         const GridDesc &g = ctx->gd;
+        const int K = ctx->ckpt;  // 0 = store every step's imaging term, K > 0 = snapshot every K steps
         int rc;
         if ((rc = upload_points(ctx, nsrc, src_idx, nrec, rec_idx))) return rc;
-        if (save && !ctx->q_store) {
+        if (save && K == 0 && !ctx->q_store) {
             const size_t bytes = (size_t)ctx->cfg.nt_max * g.npts * sizeof(T);
             size_t fr = 0, tot = 0;
             HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
             if (bytes > fr)
                 return ctx->fail(FWI_ENOMEM,
-                                 "forward-term store needs %.1f GiB (nt_max=%d) but only %.1f GiB are free",
+                                 "forward-term store needs %.1f GiB (nt_max=%d) but only %.1f GiB are free; "
+                                 "set ckpt_interval to trade it for recomputation",
                                  bytes / 1073741824.0, ctx->cfg.nt_max, fr / 1073741824.0);
             HIPCHK(ctx, hipMalloc(&ctx->q_store, bytes));
         }
-        if ((rc = ensure(ctx, &ctx->amp, &ctx->cap_amp,
-                         (size_t)nt * std::max(nsrc, nrec) * sizeof(T))))
-            return rc;
+        if (save && K > 0 && !ctx->snap) {
+            const int nseg = (ctx->cfg.nt_max + K - 1) / K;
+            HIPCHK(ctx, hipMalloc(&ctx->snap, (size_t)nseg * 2 * g.ptot * sizeof(T)));
+            HIPCHK(ctx, hipMalloc(&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T)));  // K slots + carry
+            HIPCHK(ctx, hipMalloc(&ctx->fwd[0], (size_t)g.ptot * sizeof(T)));
+            HIPCHK(ctx, hipMalloc(&ctx->fwd[1], (size_t)g.ptot * sizeof(T)));
+        }
+        if ((rc = ensure(ctx, &ctx->wav, &ctx->cap_wav, (size_t)nt * std::max(nsrc, 1) * sizeof(T)))) return rc;
+        if ((rc = ensure(ctx, &ctx->amp, &ctx->cap_amp, (size_t)nt * std::max(nrec, 1) * sizeof(T)))) return rc;
         if ((rc = ensure(ctx, &ctx->series, &ctx->cap_series,
-                         (size_t)nt * std::max(nsrc, nrec) * sizeof(T))))
+                         (size_t)nt * std::max(std::max(nsrc, nrec), 1) * sizeof(T))))
             return rc;
         ctx->nt = nt;
         ctx->nsrc = nsrc;
         ctx->nrec = nrec;
         ctx->have_forward = false;
         ctx->have_q = false;
+        hipStream_t s = ctx->stream;
         if (nsrc)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, wavelet, (size_t)nt * nsrc * sizeof(T),
-                                       hipMemcpyHostToDevice, ctx->stream));
-        rc = propagate(ctx, false, ctx->src, ctx->rec, T(1), save != 0, false);
-        if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->wav, wavelet, (size_t)nt * nsrc * sizeof(T), hipMemcpyHostToDevice, s));
+        if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
+        Sweep sw;
+        sw.f[0] = ctx->u[0];
+        sw.f[1] = ctx->u[1];
+        T *q_store = (T *)ctx->q_store;
+        T *series = (T *)ctx->series;
+        auto none = [](int) -> T * { return nullptr; };
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        if (save && K > 0) {
+            for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
+                T *sn = (T *)ctx->snap + (size_t)seg * 2 * g.ptot;  // (u^n0, u^{n0-1})
+                HIPCHK(ctx, hipMemcpyAsync(sn, sw.f[sw.cur], (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
+                HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
+                                           hipMemcpyDeviceToDevice, s));
+                if ((rc = run_steps(ctx, sw, n0, 1, std::min(K, nt - n0), ctx->src, (const T *)ctx->wav, &ctx->rec,
+                                    series, T(1), none, none)))
+                    return rc;
+            }
+        } else {
+            auto qo = [&](int n) -> T * { return save ? q_store + (size_t)n * g.npts : nullptr; };
+            if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, none)))
+                return rc;
+        }
+        if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->have_loop_time = true;
         if (nrec && seis_out)
             HIPCHK(ctx, hipMemcpyAsync(seis_out, ctx->series, (size_t)nt * nrec * sizeof(T),
-                                       hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                                       hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
         ctx->have_forward = true;
         ctx->have_q = save != 0;
         return FWI_OK;
@@ -394,16 +439,68 @@ struct Impl {
 
     static int adjoint(fwi_ctx *ctx, const T *residual, int32_t image, T *adj_src_out) {
         const GridDesc &g = ctx->gd;
+        const int nt = ctx->nt, K = ctx->ckpt;
+        hipStream_t s = ctx->stream;
+        int rc;
         if (ctx->nrec)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, residual, (size_t)ctx->nt * ctx->nrec * sizeof(T),
-                                       hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T),
+                                       hipMemcpyHostToDevice, s));
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
-        int rc = propagate(ctx, true, ctx->rec, ctx->src, rs, false, image != 0);
-        if (rc) return rc;
+        if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
+        Sweep sw;
+        sw.f[0] = ctx->u[0];
+        sw.f[1] = ctx->u[1];
+        T *q_store = (T *)ctx->q_store;
+        T *series = (T *)ctx->series;
+        const T *amp = (const T *)ctx->amp;
+        auto none = [](int) -> T * { return nullptr; };
+        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        const T *q0 = nullptr;  // q^0, for the last pairing (mu^1 with q^0)
+        if (image && K > 0) {
+            // Checkpointed: per segment (last to first) restore the snapshot, recompute the forward
+            // steps storing q into the K-slot buffer, then take the adjoint steps of that segment.
+            // Lagged imaging pairs adjoint step n with q^{n+1}: at a segment's first adjoint step that is
+            // the first q of the segment processed before, kept in the carry slot.
+            T *carry = q_store + (size_t)K * g.npts;
+            const int nseg = (nt + K - 1) / K;
+            for (int seg = nseg - 1; seg >= 0; --seg) {
+                const int n0 = seg * K, cnt = std::min(K, nt - n0);
+                const T *sn = (const T *)ctx->snap + (size_t)seg * 2 * g.ptot;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->fwd[0], sn, (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->fwd[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
+                                           hipMemcpyDeviceToDevice, s));
+                Sweep fw;
+                fw.f[0] = ctx->fwd[0];
+                fw.f[1] = ctx->fwd[1];
+                auto qo = [&](int n) -> T * { return q_store + (size_t)(n - n0) * g.npts; };
+                if ((rc = run_steps(ctx, fw, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr, T(0), qo,
+                                    none)))
+                    return rc;
+                auto qi = [&](int n) -> const T * {
+                    if (n + 1 >= nt) return nullptr;
+                    return (n + 1 < n0 + cnt) ? q_store + (size_t)(n + 1 - n0) * g.npts : carry;
+                };
+                if ((rc = run_steps(ctx, sw, n0 + cnt - 1, -1, cnt, ctx->rec, amp, &ctx->src, series, rs, none, qi)))
+                    return rc;
+                HIPCHK(ctx, hipMemcpyAsync(carry, q_store, (size_t)g.npts * sizeof(T), hipMemcpyDeviceToDevice, s));
+            }
+            q0 = carry;
+        } else {
+            auto qi = [&](int n) -> const T * {
+                return (image && n + 1 < nt) ? q_store + (size_t)(n + 1) * g.npts : nullptr;
+            };
+            if ((rc = run_steps(ctx, sw, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, none, qi))) return rc;
+            q0 = q_store;
+        }
+        if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
+        if (image)  // the last pairing: mu^1 with q^0
+            HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->have_loop_time = true;
         if (adj_src_out && ctx->nsrc)
-            HIPCHK(ctx, hipMemcpyAsync(adj_src_out, ctx->series, (size_t)ctx->nt * ctx->nsrc * sizeof(T),
-                                       hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(adj_src_out, ctx->series, (size_t)nt * ctx->nsrc * sizeof(T),
+                                       hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
         return FWI_OK;
     }
 
@@ -523,6 +620,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->dtype != FWI_F32 && cfg->dtype != FWI_F64) return bad("dtype must be FWI_F32 or FWI_F64");
     if (cfg->npml > 0 && !(cfg->sigma_max >= 0)) return bad("sigma_max must be >= 0 when npml > 0");
     if (cfg->kernel < FWI_KERNEL_AUTO || cfg->kernel > FWI_KERNEL_STREAM) return bad("unknown kernel id");
+    if (cfg->ckpt_interval < 0) return bad("ckpt_interval must be >= 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
@@ -538,6 +636,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->cfg = *cfg;
     ctx->gd = make_grid(cfg->ndim, cfg->nz, cfg->ny, cfg->nx, cfg->order);
     ctx->esize = cfg->dtype == FWI_F32 ? 4 : 8;
+    ctx->ckpt = cfg->ckpt_interval;
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
@@ -568,7 +667,8 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
-                    ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series};
+                    ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series, ctx->wav, ctx->snap, ctx->fwd[0],
+                    ctx->fwd[1]};
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
                         ps->s_cq, ps->s_col})

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 2
+#define FWI_ABI_VERSION 3
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -72,6 +72,11 @@ typedef struct fwi_config {
     int32_t dtype;       /* FWI_F32 or FWI_F64 */
     int32_t kernel;      /* FWI_KERNEL_* */
     int32_t zchunk;      /* 3-D STREAM kernel: planes marched per workgroup; 0 = auto */
+    int32_t ckpt_interval; /* 0: keep the imaging term of every step (nt_max x npts elements);
+                              K > 0: snapshot the wavefields every K steps and recompute each
+                              K-step forward segment during fwi_adjoint (one extra forward sweep,
+                              ~(2 nt_max / K + K) x npts elements)  [SURVEY s.8f-3] */
+    int32_t reserved;    /* keep 0 */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the sponge, >= 0 (used when npml > 0) */

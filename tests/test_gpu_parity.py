@@ -308,3 +308,27 @@ def test_2d_tile_kernel_matches_point_kernel(gpu):
     assert a["kernel"] == "step_point" and b["kernel"] == "step2d_tile"
     assert rel(b["seis"], a["seis"]) < 2e-6
     assert w.ndim == 2
+
+
+@pytest.mark.parametrize("shape,K", [((40, 36, 44), 7), ((40, 36, 44), 1), ((40, 36, 44), 500), ((96, 100), 16)])
+def test_checkpointed_gradient_equals_store_all(gpu, shape, K):
+    """SURVEY s.8f-3: snapshots every K steps + recomputation give the store-all gradient
+    (K not dividing nt, K = 1, K > nt; 3-D stream kernel and 2-D tile kernel)."""
+    rng = np.random.default_rng(11)
+    nd = len(shape)
+    c = 1800.0 + 1200.0 * rng.random(shape)
+    dt = 0.7 * fo.cfl_dt(c.max(), 8.0, nd, 8)
+    nt = 90
+    src = np.array([[s // 2 for s in shape], [s // 3 for s in shape]])
+    rec = np.stack([rng.integers(0, s, 17) for s in shape], 1)
+    wav = np.stack([fo.ricker(nt, dt, 22.0), -0.5 * fo.ricker(nt, dt, 16.0)], 1).astype(np.float32)
+    out = []
+    for ck in (0, K):
+        with Engine(shape, 8.0, dt, nt, order=8, npml=5, sigma_max=700.0, ckpt_interval=ck) as e:
+            d = e.forward(c, (src, wav), rec, save=True)
+            r = (d * rng.standard_normal(1)).astype(np.float32) if not out else out[0][2]
+            a = e.adjoint(r)
+            out.append((d, a, r, e.gradient()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert rel(out[1][1], out[0][1]) < 1e-6
+    assert rel(out[1][3], out[0][3]) < 1e-6
