@@ -42,7 +42,7 @@ struct fwi_ctx {
     fwi_config cfg;
     GridDesc gd;
     int kernel = K_POINT;
-    StreamTuning tune{8, 0};
+    StreamTuning tune{8, 0, 2};
     size_t esize = 4;  // bytes per element
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -646,6 +646,10 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (ctx->kernel == K_STREAM) {
         ctx->tune = stream_default_tuning(ctx->gd);
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
+        if (const char *pf = getenv("FWI_STREAM_PF")) {  // tuning hook: prefetch depth in planes
+            const int v = atoi(pf);
+            if (v >= 1 && v <= 3) ctx->tune.pf = v;
+        }
         if (const char *ty = getenv("FWI_STREAM_TY")) {  // tuning hook: rows per workgroup
             const int v = atoi(ty);
             if (v == 4 || v == 8 || (v == 16 && cfg->ndim == 2)) ctx->tune.ty = v;

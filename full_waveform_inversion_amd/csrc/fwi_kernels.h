@@ -61,6 +61,7 @@ enum StencilKernel { K_POINT = 1, K_STREAM = 2 };
 struct StreamTuning {
     int ty;      // rows per workgroup (4 or 8)
     int zchunk;  // planes marched per workgroup
+    int pf;      // planes fetched ahead of use (1..3)
 };
 
 // Workgroup tile of the stream kernel that owns grid point (z, y, x): the index

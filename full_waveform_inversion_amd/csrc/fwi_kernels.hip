@@ -154,7 +154,7 @@ __device__ __forceinline__ float rcp_nr(float a) {
 constexpr int TILE_X = 256;                // floats per tile row = 64 lanes x float4
 constexpr int LROW4 = TILE_X / 4 + 2;      // LDS row in float4: [left edge][64][right edge]
 
-template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE, bool FULL>
+template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE, bool FULL, int PF>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -225,29 +225,36 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
         }
     }
 
-    // z register queue of NQ = 2R+2 slots: plane p lives in slot (p - z0 + R) % NQ, one slot
-    // more than the stencil needs so the next plane is fetched straight into the queue.
-    // The z loop is unrolled NQ times: every queue / double-buffer index below is a
-    // compile-time constant, so there are no register rotations and hipcc can keep the
-    // prefetches of plane z+1 in flight while plane z is computed (exact vmcnt counts).
-    constexpr int NQ = 2 * R + 2;
+    // z register queue: plane p lives in slot (p - z0 + R) % NQ.  PF planes are fetched ahead of
+    // use straight into the queue; the pointwise operands (u_prev, C), halo rows and edge pieces
+    // sit in rings of PF + 1 slots.  NQ is a multiple of PF + 1 and the z loop is unrolled NQ
+    // times, so every queue / ring index below is a compile-time constant: no register
+    // rotations, and hipcc keeps the prefetches of planes z+1 .. z+PF in flight while plane z is
+    // computed (exact vmcnt counts).  PF >= 2 matters at one wave per SIMD: one plane takes
+    // ~0.6 us, less than a loaded L2-miss round trip.
+    constexpr int NR = PF + 1;
+    constexpr int NQ = (2 * R + 1 + PF + NR - 1) / NR * NR;
     f4 zq[NQ];
 #pragma unroll
-    for (int k = 0; k <= 2 * R; ++k) zq[k] = ld4(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
-    f4 up[2], Cc[2], halo[2][NH];
-    float edge[2];
-    up[0] = ld4(a.u_prev + (int64_t)z0 * sz + poff);
-    Cc[0] = ld4(a.C + (int64_t)z0 * sz + poff);
+    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ld4(a.u_cur + (int64_t)min(z0 - R + k, zlast) * sz + poff);
+    f4 up[NR], Cc[NR], halo[NR][NH];
+    float edge[NR];
 #pragma unroll
-    for (int i = 0; i < NH; ++i) halo[0][i] = ld4(a.u_cur + (int64_t)z0 * sz + hoff[i]);
-    edge[0] = a.u_cur[(int64_t)z0 * sz + eoff];
+    for (int p = 0; p < PF; ++p) {
+        const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
+        up[p] = ld4(a.u_prev + o + poff);
+        Cc[p] = ld4(a.C + o + poff);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) halo[p][i] = ld4(a.u_cur + o + hoff[i]);
+        edge[p] = a.u_cur[o + eoff];
+    }
 
     for (int zb = z0; zb < z1; zb += NQ) {
 #pragma unroll
         for (int ph = 0; ph < NQ; ++ph) {
             const int z = zb + ph;
             if (z >= z1) break;
-            const int cur = ph & 1, nxt = cur ^ 1;  // NQ is even: parity is static
+            const int cur = ph % NR, nxt = (ph + PF) % NR;  // NQ % NR == 0: static across blocks
             // slot of plane z - R + k is (ph + k) % NQ
             const f4 &ctr = zq[(ph + R) % NQ];
 
@@ -258,9 +265,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[cur][i];
             reinterpret_cast<float *>(&L[erow][0])[ecol] = edge[cur];
 
-            // fetch plane z+1's operands (and plane z+R+1 of the queue) while z is computed
-            const int64_t on = (int64_t)min(z + 1, zlast) * sz;
-            zq[(ph + 2 * R + 1) % NQ] = ld4(a.u_cur + (int64_t)min(z + R + 1, zlast) * sz + poff);
+            // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
+            const int64_t on = (int64_t)min(z + PF, zlast) * sz;
+            zq[(ph + 2 * R + PF) % NQ] = ld4(a.u_cur + (int64_t)min(z + R + PF, zlast) * sz + poff);
 #pragma unroll
             for (int i = 0; i < NH; ++i) halo[nxt][i] = ld4(a.u_cur + on + hoff[i]);
             edge[nxt] = a.u_cur[on + eoff];
@@ -490,24 +497,24 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g) {
-    if (g.ndim == 2) return StreamTuning{16, 1};  // rows per workgroup (measured best of 4/8/16); no marching axis
+    if (g.ndim == 2) return StreamTuning{16, 1, 2};  // rows per workgroup (measured best of 4/8/16); no marching axis
     // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
     // (about one per CU, 256 CUs) each marching as many planes as possible, because every
     // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
     // (256 workgroups) 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256 328 vs TY 4 x 256 302
     // (8 rows per tile halve the y-halo re-read once the z chunks are long anyway).
-    StreamTuning best{4, g.nz};
+    StreamTuning best{4, g.nz, 2};
     for (int ty : {8, 4}) {
         const int64_t tiles_xy = stream_nxt(g) * (round_up(g.ny, ty) / ty);
         const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
         const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
-        best = StreamTuning{ty, zc};
+        best = StreamTuning{ty, zc, 2};
         if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
     }
     return best;
 }
 
-template <int R, int TY, bool DAMP, bool FULL>
+template <int R, int TY, bool DAMP, bool FULL, int PF>
 static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a, int zchunk,
                                      hipStream_t s) {
     const int nxt = (int)(round_up(g.nx, TILE_X) / TILE_X);
@@ -517,23 +524,30 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
     dim3 block(64, TY), grid(nblk + nrb);
     if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true, FULL>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false, FULL>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     return hipGetLastError();
 }
 
 template <int R, int TY, bool DAMP>
-static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk,
+static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk, int pf,
                                      hipStream_t s) {
-    // FULL: every thread of every tile owns grid points, so the stores need no predicate
-    if (g.nx % TILE_X == 0 && g.ny % TY == 0) return launch_stream_full<R, TY, DAMP, true>(g, a, zchunk, s);
-    return launch_stream_full<R, TY, DAMP, false>(g, a, zchunk, s);
+    // FULL: every thread of every tile owns grid points, so the stores need no predicate.
+    // The prefetch depth is a tuning knob of the O(8) kernel only.
+    if (g.nx % TILE_X == 0 && g.ny % TY == 0) {
+        if constexpr (R == 4) {
+            if (pf == 1) return launch_stream_full<R, TY, DAMP, true, 1>(g, a, zchunk, s);
+            if (pf == 3) return launch_stream_full<R, TY, DAMP, true, 3>(g, a, zchunk, s);
+        }
+        return launch_stream_full<R, TY, DAMP, true, 2>(g, a, zchunk, s);
+    }
+    return launch_stream_full<R, TY, DAMP, false, 2>(g, a, zchunk, s);
 }
 
 template <int R>
@@ -542,13 +556,13 @@ static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, c
     const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
     if (a.damp) {
         switch (t.ty) {
-            case 4: return launch_stream_mode<R, 4, true>(g, a, zc, s);
-            default: return launch_stream_mode<R, 8, true>(g, a, zc, s);
+            case 4: return launch_stream_mode<R, 4, true>(g, a, zc, t.pf, s);
+            default: return launch_stream_mode<R, 8, true>(g, a, zc, t.pf, s);
         }
     }
     switch (t.ty) {
-        case 4: return launch_stream_mode<R, 4, false>(g, a, zc, s);
-        default: return launch_stream_mode<R, 8, false>(g, a, zc, s);
+        case 4: return launch_stream_mode<R, 4, false>(g, a, zc, t.pf, s);
+        default: return launch_stream_mode<R, 8, false>(g, a, zc, t.pf, s);
     }
 }
 

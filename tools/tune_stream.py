@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--ty", default="4,8")
     ap.add_argument("--zchunk", default="16,32,64,128,256")
+    ap.add_argument("--pf", default="2", help="prefetch depths to sweep (1..3)")
     ap.add_argument("--point", type=int, default=1)
     ap.add_argument("--mode", default="forward", choices=["forward", "save", "adjoint"],
                     help="forward: plain steps; save: forward storing the imaging term; "
@@ -31,15 +32,17 @@ def main():
     w.nt = a.nt
     wav = w.wavelet()
     model = w.c.astype(np.float32)
-    variants = [("point", 0, 0)] if a.point else []
-    for ty in map(int, a.ty.split(",")):
-        for zc in map(int, a.zchunk.split(",")):
-            if zc <= a.grid:
-                variants.append(("stream", ty, zc))
+    variants = [("point", 0, 0, 0)] if a.point else []
+    for pf in map(int, a.pf.split(",")):
+        for ty in map(int, a.ty.split(",")):
+            for zc in map(int, a.zchunk.split(",")):
+                if zc <= a.grid:
+                    variants.append(("stream", ty, zc, pf))
     engines = []
-    for k, ty, zc in variants:
+    for k, ty, zc, pf in variants:
         if ty:
             os.environ["FWI_STREAM_TY"] = str(ty)
+            os.environ["FWI_STREAM_PF"] = str(pf)
         e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, kernel=k, zchunk=zc)
         e.set_model(model)
         engines.append(e)
@@ -62,12 +65,12 @@ def main():
     npts = int(np.prod(w.shape))
     bpp = {"forward": 16, "save": 20, "adjoint": 28}[a.mode]  # SURVEY.md s.8d algorithmic bytes/update
     print("grid %d^3 nt %d npml %d mode %s (%d B/update)" % (a.grid, a.nt, a.npml, a.mode, bpp))
-    print("%-8s %3s %6s %10s %10s %8s %8s" % ("kernel", "ty", "zchunk", "us/step", "Gpts/s", "GB/s", "frac8T"))
+    print("%-8s %3s %6s %2s %10s %10s %8s %8s" % ("kernel", "ty", "zchunk", "pf", "us/step", "Gpts/s", "GB/s", "frac8T"))
     for v in variants:
         ms = float(np.median(res[v]))
         us = 1e3 * ms / a.nt
         g = npts / us / 1e3
-        print("%-8s %3d %6d %10.2f %10.1f %8.0f %8.3f" % (v[0], v[1], v[2], us, g, bpp * g, bpp * g / 8000))
+        print("%-8s %3d %6d %2d %10.2f %10.1f %8.0f %8.3f" % (v[0], v[1], v[2], v[3], us, g, bpp * g, bpp * g / 8000))
 
 
 if __name__ == "__main__":
