@@ -42,7 +42,7 @@ struct fwi_ctx {
     fwi_config cfg;
     GridDesc gd;
     int kernel = K_POINT;
-    StreamTuning tune{8, 0, 2};
+    StreamTuning tune{8, 0, 1};
     size_t esize = 4;  // bytes per element
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

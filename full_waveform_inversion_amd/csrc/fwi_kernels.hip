@@ -232,21 +232,31 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     // rotations, and hipcc keeps the prefetches of planes z+1 .. z+PF in flight while plane z is
     // computed (exact vmcnt counts).  PF >= 2 matters at one wave per SIMD: one plane takes
     // ~0.6 us, less than a loaded L2-miss round trip.
+    // The y-halo rows are fetched R planes ahead (ring of R + 1 slots, which divides NQ): that is
+    // (almost) when the neighbouring tile, whose interior rows they are, streams the same plane
+    // into its own z queue, so the second request hits in the XCD's L2 instead of going back to
+    // HBM ~4 planes later (measured at 512^3: traffic 1.235x algorithmic before).
     constexpr int NR = PF + 1;
     constexpr int NQ = (2 * R + 1 + PF + NR - 1) / NR * NR;
+    constexpr int HPF = (NQ % (R + 1) == 0) ? R : PF;  // halo prefetch distance
+    constexpr int NRH = HPF + 1;
     f4 zq[NQ];
 #pragma unroll
     for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ld4(a.u_cur + (int64_t)min(z0 - R + k, zlast) * sz + poff);
-    f4 up[NR], Cc[NR], halo[NR][NH];
+    f4 up[NR], Cc[NR], halo[NRH][NH];
     float edge[NR];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
         up[p] = ld4(a.u_prev + o + poff);
         Cc[p] = ld4(a.C + o + poff);
+        edge[p] = a.u_cur[o + eoff];
+    }
+#pragma unroll
+    for (int p = 0; p < HPF; ++p) {
+        const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
 #pragma unroll
         for (int i = 0; i < NH; ++i) halo[p][i] = ld4(a.u_cur + o + hoff[i]);
-        edge[p] = a.u_cur[o + eoff];
     }
 
     for (int zb = z0; zb < z1; zb += NQ) {
@@ -262,14 +272,17 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             f4(*L)[LROW4] = lds[z & 1];
             L[R + ty][1 + lane] = ctr;
 #pragma unroll
-            for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[cur][i];
+            for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[ph % NRH][i];
             reinterpret_cast<float *>(&L[erow][0])[ecol] = edge[cur];
 
             // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
             const int64_t on = (int64_t)min(z + PF, zlast) * sz;
             zq[(ph + 2 * R + PF) % NQ] = ld4(a.u_cur + (int64_t)min(z + R + PF, zlast) * sz + poff);
+            {
+                const int64_t oh = (int64_t)min(z + HPF, zlast) * sz;
 #pragma unroll
-            for (int i = 0; i < NH; ++i) halo[nxt][i] = ld4(a.u_cur + on + hoff[i]);
+                for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ld4(a.u_cur + oh + hoff[i]);
+            }
             edge[nxt] = a.u_cur[on + eoff];
             up[nxt] = ld4(a.u_prev + on + poff);
             Cc[nxt] = ld4(a.C + on + poff);
@@ -497,18 +510,18 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g) {
-    if (g.ndim == 2) return StreamTuning{16, 1, 2};  // rows per workgroup (measured best of 4/8/16); no marching axis
+    if (g.ndim == 2) return StreamTuning{16, 1, 1};  // rows per workgroup (measured best of 4/8/16); no marching axis
     // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
     // (about one per CU, 256 CUs) each marching as many planes as possible, because every
     // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
     // (256 workgroups) 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256 328 vs TY 4 x 256 302
     // (8 rows per tile halve the y-halo re-read once the z chunks are long anyway).
-    StreamTuning best{4, g.nz, 2};
+    StreamTuning best{4, g.nz, 1};
     for (int ty : {8, 4}) {
         const int64_t tiles_xy = stream_nxt(g) * (round_up(g.ny, ty) / ty);
         const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
         const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
-        best = StreamTuning{ty, zc, 2};
+        best = StreamTuning{ty, zc, 1};
         if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
     }
     return best;
@@ -540,14 +553,12 @@ static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a
                                      hipStream_t s) {
     // FULL: every thread of every tile owns grid points, so the stores need no predicate.
     // The prefetch depth is a tuning knob of the O(8) kernel only.
-    if (g.nx % TILE_X == 0 && g.ny % TY == 0) {
-        if constexpr (R == 4) {
-            if (pf == 1) return launch_stream_full<R, TY, DAMP, true, 1>(g, a, zchunk, s);
-            if (pf == 3) return launch_stream_full<R, TY, DAMP, true, 3>(g, a, zchunk, s);
-        }
-        return launch_stream_full<R, TY, DAMP, true, 2>(g, a, zchunk, s);
-    }
-    return launch_stream_full<R, TY, DAMP, false, 2>(g, a, zchunk, s);
+    // Prefetch depth: PF = 1 plane ahead measured best (256^3: 39.5 us/step vs 40.0 / 40.2 for
+    // PF = 2 / 3; 512^3 equal), i.e. the kernel is throughput- not latency-bound; deeper rings
+    // only cost registers.  The template parameter stays for re-tuning.
+    (void)pf;
+    if (g.nx % TILE_X == 0 && g.ny % TY == 0) return launch_stream_full<R, TY, DAMP, true, 1>(g, a, zchunk, s);
+    return launch_stream_full<R, TY, DAMP, false, 1>(g, a, zchunk, s);
 }
 
 template <int R>
