@@ -15,6 +15,7 @@
 #include "fwi_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace fwi {
 
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
         return;
     }
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous slabs
+    if ((nblk & 7) == 0 && zchunk > 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous slabs
+    zchunk = abs(zchunk);  // (a negative zchunk is the tuning hook that switches the renumbering off)
     const int bx = bid % nxt;
     const int t2 = bid / nxt;
     const int by = t2 % nyt, bz = t2 / nyt;
@@ -284,6 +286,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
                 for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ld4(a.u_cur + oh + hoff[i]);
             }
             edge[nxt] = a.u_cur[on + eoff];
+            // (plain loads: non-temporal hints on these read-once streams were measured and
+            // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
             up[nxt] = ld4(a.u_prev + on + poff);
             Cc[nxt] = ld4(a.C + on + poff);
             f4 qi, gi;
@@ -536,6 +540,8 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a
     const int nblk = nxt * nyt * nzc;
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
     dim3 block(64, TY), grid(nblk + nrb);
+    static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
+    if (no_remap) zchunk = -zchunk;
     if (a.q_out)
         hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
