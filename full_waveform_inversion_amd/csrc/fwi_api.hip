@@ -168,6 +168,7 @@ struct Impl {
         a.dx = (const T *)ctx->dx;
         a.q_out = nullptr;
         a.q_in = nullptr;
+        a.q_in2 = nullptr;
         a.g = (T *)ctx->g_acc;
         const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
@@ -327,7 +328,7 @@ struct Impl {
             a.u_cur = (const T *)sw.f[sw.cur];
             a.u_prev = (T *)sw.f[sw.cur ^ 1];
             a.q_out = q_out(n);
-            a.q_in = q_in(n);
+            q_in(n, a.q_in, a.q_in2);
             if (inj.n > 0) {
                 a.inj_start = (const int *)inj.s_start;
                 a.inj_pidx = (const int64_t *)inj.s_pidx;
@@ -409,6 +410,7 @@ struct Impl {
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         auto none = [](int) -> T * { return nullptr; };
+        auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         if (save && K > 0) {
             for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
@@ -417,12 +419,12 @@ struct Impl {
                 HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));
                 if ((rc = run_steps(ctx, sw, n0, 1, std::min(K, nt - n0), ctx->src, (const T *)ctx->wav, &ctx->rec,
-                                    series, T(1), none, none)))
+                                    series, T(1), none, noq)))
                     return rc;
             }
         } else {
             auto qo = [&](int n) -> T * { return save ? q_store + (size_t)n * g.npts : nullptr; };
-            if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, none)))
+            if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, noq)))
                 return rc;
         }
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
@@ -454,13 +456,37 @@ struct Impl {
         T *series = (T *)ctx->series;
         const T *amp = (const T *)ctx->amp;
         auto none = [](int) -> T * { return nullptr; };
+        auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         const T *q0 = nullptr;  // q^0, for the last pairing (mu^1 with q^0)
+        // Lagged imaging: adjoint step n (which reads mu^{n+2} as u_cur and mu^{n+3} as u_prev) owns
+        // the pairing P(n) = (mu^{n+2}, q^{n+1}).  Steps are taken in pairs: P(n+1) is deferred and
+        // taken at step n together with P(n) -- u_prev there is still mu^{n+3} -- so the gradient
+        // accumulator is read and written every other step only.  plan() fills, for the steps
+        // n = hi .. lo (descending) of one run, the q pointers of P(n) and of a deferred P(n+1).
+        std::vector<const T *> pq, pq2;
+        auto plan = [&](int hi, int lo, auto qptr /* n -> q^{n+1} or nullptr */) {
+            pq.assign(hi - lo + 1, nullptr);
+            pq2.assign(hi - lo + 1, nullptr);
+            const T *pending = nullptr;  // deferred pairing of the step above
+            for (int n = hi; n >= lo; --n) {
+                const T *mine = qptr(n);
+                if (pending) {  // second step of a pair: take both (mine is valid whenever pending is)
+                    pq[hi - n] = mine;
+                    pq2[hi - n] = pending;
+                    pending = nullptr;
+                } else if (mine && n > lo) {
+                    pending = mine;  // first step of a pair: defer
+                } else {
+                    pq[hi - n] = mine;  // single (last step of an odd run, or nothing to pair)
+                }
+            }
+        };
         if (image && K > 0) {
             // Checkpointed: per segment (last to first) restore the snapshot, recompute the forward
             // steps storing q into the K-slot buffer, then take the adjoint steps of that segment.
-            // Lagged imaging pairs adjoint step n with q^{n+1}: at a segment's first adjoint step that is
-            // the first q of the segment processed before, kept in the carry slot.
+            // At a segment's first adjoint step q^{n+1} is the first q of the segment processed
+            // before, kept in the carry slot.
             T *carry = q_store + (size_t)K * g.npts;
             const int nseg = (nt + K - 1) / K;
             for (int seg = nseg - 1; seg >= 0; --seg) {
@@ -474,21 +500,24 @@ struct Impl {
                 fw.f[1] = ctx->fwd[1];
                 auto qo = [&](int n) -> T * { return q_store + (size_t)(n - n0) * g.npts; };
                 if ((rc = run_steps(ctx, fw, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr, T(0), qo,
-                                    none)))
+                                    noq)))
                     return rc;
-                auto qi = [&](int n) -> const T * {
+                const int hi = n0 + cnt - 1;
+                plan(hi, n0, [&](int n) -> const T * {
                     if (n + 1 >= nt) return nullptr;
                     return (n + 1 < n0 + cnt) ? q_store + (size_t)(n + 1 - n0) * g.npts : carry;
-                };
-                if ((rc = run_steps(ctx, sw, n0 + cnt - 1, -1, cnt, ctx->rec, amp, &ctx->src, series, rs, none, qi)))
+                });
+                auto qi = [&](int n, const T *&p, const T *&p2) { p = pq[hi - n]; p2 = pq2[hi - n]; };
+                if ((rc = run_steps(ctx, sw, hi, -1, cnt, ctx->rec, amp, &ctx->src, series, rs, none, qi)))
                     return rc;
                 HIPCHK(ctx, hipMemcpyAsync(carry, q_store, (size_t)g.npts * sizeof(T), hipMemcpyDeviceToDevice, s));
             }
             q0 = carry;
         } else {
-            auto qi = [&](int n) -> const T * {
+            plan(nt - 1, 0, [&](int n) -> const T * {
                 return (image && n + 1 < nt) ? q_store + (size_t)(n + 1) * g.npts : nullptr;
-            };
+            });
+            auto qi = [&](int n, const T *&p, const T *&p2) { p = pq[nt - 1 - n]; p2 = pq2[nt - 1 - n]; };
             if ((rc = run_steps(ctx, sw, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, none, qi))) return rc;
             q0 = q_store;
         }

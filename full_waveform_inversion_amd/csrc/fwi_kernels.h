@@ -35,6 +35,8 @@ struct StepArgs {
     const T *dz, *dy, *dx;  // per-axis damping d = sigma dt / 2 (lengths nz, ny, nx)
     T *q_out;        // compact (npts) forward term of this step, or nullptr
     const T *q_in;   // compact forward term to correlate u_cur with, or nullptr
+    const T *q_in2;  // second pairing taken in the same launch: u_prev (before it is overwritten) with
+                     // this term, so the gradient accumulator is read-modified-written every other step
     T *g;            // compact gradient accumulator (used with q_in)
     T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
     int damp;        // npml > 0

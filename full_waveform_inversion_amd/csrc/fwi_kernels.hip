@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
         a.u_prev[p] = un;
         const int64_t ci = ((int64_t)z * g.ny + y) * g.nx + x;
         if (SAVE_Q) a.q_out[ci] = q;
-        if (IMAGE) a.g[ci] += uc * a.q_in[ci];
+        if (IMAGE) a.g[ci] += a.q_in2 ? fma(up, a.q_in2[ci], uc * a.q_in[ci]) : uc * a.q_in[ci];
     }
     // injection into the points this workgroup has just written (see the stream kernel)
     if (a.inj_start) {
@@ -155,7 +155,9 @@ __device__ __forceinline__ float rcp_nr(float a) {
 constexpr int TILE_X = 256;                // floats per tile row = 64 lanes x float4
 constexpr int LROW4 = TILE_X / 4 + 2;      // LDS row in float4: [left edge][64][right edge]
 
-template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE, bool FULL, int PF>
+// IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
+// read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
+template <int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -290,10 +292,11 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
             up[nxt] = ld4(a.u_prev + on + poff);
             Cc[nxt] = ld4(a.C + on + poff);
-            f4 qi, gi;
+            f4 qi, qi2, gi;
             if (IMAGE) {
                 const unsigned co = act ? coff : 0u;
                 qi = ld4_stream(a.q_in + (int64_t)z * cplane + co);
+                if (IMAGE == 2) qi2 = ld4_stream(a.q_in2 + (int64_t)z * cplane + co);
                 gi = ld4(a.g + (int64_t)z * cplane + co);
             }
             __syncthreads();
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
                 if (SAVE_Q) st4_stream(a.q_out + (int64_t)z * cplane + coff, q);
                 if (IMAGE) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+                        if (IMAGE == 2) gi.v[j] = fmaf(up[cur].v[j], qi2.v[j], gi.v[j]);
+                    }
                     st4(a.g + (int64_t)z * cplane + coff, gi);
                 }
             }
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
 // L2-resident (1024^2: 4 MiB per field), so a time step is bounded by the ~1.5 us kernel boundary
 // plus one load -> barrier -> compute -> store chain; there is no marching axis to pipeline.
 // ---------------------------------------------------------------------------
-template <int R, int TY, bool DAMP, bool SAVE_Q, bool IMAGE>
+template <int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE>
 __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDesc g, int nxt, int nblk) {
     constexpr int NH = (2 * R + TY - 1) / TY;
     constexpr int TRASH = TY + 2 * R;
@@ -421,9 +427,10 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     const float edge = a.u_cur[eoff];
     const f4 up = ld4(a.u_prev + poff), Cc = ld4(a.C + poff);
     const int64_t ci = (int64_t)z * g.nx + x0;
-    f4 qi, gi;
+    f4 qi, qi2, gi;
     if (IMAGE) {
         qi = ld4_stream(a.q_in + (act ? ci : 0));
+        if (IMAGE == 2) qi2 = ld4_stream(a.q_in2 + (act ? ci : 0));
         gi = ld4(a.g + (act ? ci : 0));
     }
     f4 A, B;
@@ -479,7 +486,10 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
         if (SAVE_Q) st4_stream(a.q_out + ci, q);
         if (IMAGE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+            for (int j = 0; j < 4; ++j) {
+                gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
+                if (IMAGE == 2) gi.v[j] = fmaf(up.v[j], qi2.v[j], gi.v[j]);
+            }
             st4(a.g + ci, gi);
         }
     }
@@ -543,13 +553,16 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a
     static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
     if (no_remap) zchunk = -zchunk;
     if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, false, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
+                           zchunk, nxt, nyt, nblk);
+    else if (a.q_in && a.q_in2)
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, true, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, false, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     return hipGetLastError();
 }
@@ -590,11 +603,13 @@ static hipError_t launch_tile2d_mode(const GridDesc &g, const StepArgs<float> &a
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
     dim3 block(64, TY), grid(nblk + nrb);
     if (a.q_out)
-        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, true, false>), grid, block, 0, s, a, g, nxt, nblk);
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, true, 0>), grid, block, 0, s, a, g, nxt, nblk);
+    else if (a.q_in && a.q_in2)
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, 2>), grid, block, 0, s, a, g, nxt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, true>), grid, block, 0, s, a, g, nxt, nblk);
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, 1>), grid, block, 0, s, a, g, nxt, nblk);
     else
-        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, false>), grid, block, 0, s, a, g, nxt, nblk);
+        hipLaunchKernelGGL((step2d_tile<R, TY, DAMP, false, 0>), grid, block, 0, s, a, g, nxt, nblk);
     return hipGetLastError();
 }
 
