@@ -144,7 +144,8 @@ def main():
     if rank == 0:
         npts = int(np.prod(w.shape))
         sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
-        bpu = (20 + 28) / 2.0 if grad else BYTES_PER_UPDATE  # SURVEY s.8d: save 20 B, adjoint+imaging 28 B
+        # forward+save 20 B; adjoint + paired imaging 24 B (SURVEY s.8d prices the unpaired form at 28 B)
+        bpu = (20 + 24) / 2.0 if grad else BYTES_PER_UPDATE
         updates = npts * w.nt * sweeps
         value = world * args.steps * updates / el / 1e9
         kern_us = 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps)  # avg launch-to-launch time per step kernel

@@ -40,7 +40,7 @@ def main():
                 out.setdefault(k, []).append(v)
     print("%s %s nt=%d order=%d npml=%d kernel=%s dtype=%s" % (w.name, w.shape, w.nt, w.order, w.npml,
                                                             e.kernel_name, a.dtype))
-    for k, bpp in (("forward", 16), ("save", 20), ("adjoint", 28)):
+    for k, bpp in (("forward", 16), ("save", 20), ("adjoint", 24)):  # adjoint: paired imaging
         us = 1e3 * float(np.median(out[k])) / w.nt
         g = npts / us / 1e3
         print("  %-8s %8.2f us/step %8.1f Gpts/s  %6.0f GB/s algorithmic (%d B/update x%s)" % (

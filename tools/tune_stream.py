@@ -63,7 +63,7 @@ def main():
             if err > 1e-5:
                 print("MISMATCH", v, err)
     npts = int(np.prod(w.shape))
-    bpp = {"forward": 16, "save": 20, "adjoint": 28}[a.mode]  # SURVEY.md s.8d algorithmic bytes/update
+    bpp = {"forward": 16, "save": 20, "adjoint": 24}[a.mode]  # bytes/update (adjoint: paired imaging; SURVEY s.8d: 28 unpaired)
     print("grid %d^3 nt %d npml %d mode %s (%d B/update)" % (a.grid, a.nt, a.npml, a.mode, bpp))
     print("%-8s %3s %6s %2s %10s %10s %8s %8s" % ("kernel", "ty", "zchunk", "pf", "us/step", "Gpts/s", "GB/s", "frac8T"))
     for v in variants:
