@@ -82,8 +82,14 @@ def model_data(engine, model, shots, exchange=None):
     return shots
 
 
-def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity"):
-    """J = 1/2 sum_shots ||F_s(model) - d_obs,s||^2 and dJ/dmodel, summed over all ranks."""
+def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", objective=None):
+    """J = sum_shots objective(F_s(model), d_obs,s) and dJ/dmodel, summed over all ranks.
+
+    ``objective(d_syn, d_obs) -> (J, dJ/dd_syn)``; default least squares 1/2 ||d_syn - d_obs||^2
+    (see objectives.py for the reference's similarity measures as misfits).
+    """
+    from .objectives import l2
+    objective = objective or l2
     ex = exchange or NoExchange()
     engine.set_model(model)
     engine.reset_gradient()
@@ -93,7 +99,7 @@ def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity"):
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
         d = engine.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
-        r = d - s.d_obs
-        misfit += 0.5 * float(np.vdot(r.astype(np.float64), r.astype(np.float64)))
+        j, r = objective(d, s.d_obs)
+        misfit += j
         engine.adjoint(r)
     return ex.reduce(engine, misfit, wrt)[::-1]
