@@ -59,7 +59,7 @@ struct fwi_ctx {
     double *red = nullptr;    // reduction scalars
 
     // host copies
-    std::vector<double> c_host, pz, py, px;
+    std::vector<double> pz, py, px;
     bool have_model = false;
 
     // per-shot point sets (device) and their sizes
@@ -190,34 +190,28 @@ struct Impl {
 
     static int set_model(fwi_ctx *ctx, const T *c) {
         const GridDesc &g = ctx->gd;
-        ctx->c_host.resize(g.npts);
-        std::vector<T> Cpad((size_t)g.ptot, T(0));
-        const double dt2 = ctx->cfg.dt * ctx->cfg.dt;
-        for (int z = 0; z < g.nz; ++z)
-            for (int y = 0; y < g.ny; ++y) {
-                const int64_t ci = ((int64_t)z * g.ny + y) * g.nx;
-                const int64_t pi = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy;
-                for (int x = 0; x < g.nx; ++x) {
-                    const double cv = (double)c[ci + x];
-                    if (!(cv > 0.0) || !std::isfinite(cv))
-                        return ctx->fail(FWI_EINVAL, "velocity must be finite and > 0");
-                    ctx->c_host[ci + x] = cv;
-                    Cpad[pi + x] = (T)(dt2 * cv * cv);
-                }
-            }
-        HIPCHK(ctx, hipMemcpyAsync(ctx->C, Cpad.data(), (size_t)g.ptot * sizeof(T),
-                                   hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, c, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice,
-                                   ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->have_model = true;
+        hipStream_t s = ctx->stream;
+        // compact H2D copy, then validation + padded C = dt^2 c^2 on the device (the halo of C
+        // was zeroed at creation and is never written)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, c, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice, s));
+        int *bad = (int *)(ctx->red + 4);
+        HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), s));
+        HIPCHK(ctx, launch_build_model<T>(g, (const T *)ctx->c_dev, (T *)ctx->C, ctx->cfg.dt * ctx->cfg.dt, bad, s));
+        int nbad = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
         ctx->have_forward = false;
+        if (nbad) {
+            ctx->have_model = false;
+            return ctx->fail(FWI_EINVAL, "velocity must be finite and > 0 (%d bad entries)", nbad);
+        }
+        ctx->have_model = true;
         return FWI_OK;
     }
 
     // coefficient of an injected amplitude in u (A*C*scale) and in q (C*scale)
-    static void point_coefs(fwi_ctx *ctx, const int32_t *idx, int n, double scale, std::vector<T> &cu,
-                            std::vector<T> &cq) {
+    static void point_coefs(fwi_ctx *ctx, const int32_t *idx, int n, double scale, const std::vector<T> &cpt,
+                            std::vector<T> &cu, std::vector<T> &cq) {
         const GridDesc &g = ctx->gd;
         const double dt2 = ctx->cfg.dt * ctx->cfg.dt;
         cu.resize(n);
@@ -225,7 +219,7 @@ struct Impl {
         for (int i = 0; i < n; ++i) {
             const int32_t *t = idx + (size_t)i * g.ndim;
             const int z = t[0], y = (g.ndim == 3) ? t[1] : 0, x = t[g.ndim - 1];
-            const double cv = ctx->c_host[((int64_t)z * g.ny + y) * g.nx + x];
+            const double cv = (double)cpt[i];
             const double d = ctx->pz[z] + ((g.ndim == 3) ? ctx->py[y] : 0.0) + ctx->px[x];
             const double Cv = (double)(T)(dt2 * cv * cv);  // as the kernels see it
             cq[i] = (T)(Cv * scale);
@@ -239,8 +233,6 @@ struct Impl {
         std::vector<int64_t> p, c;
         int rcode;
         if ((rcode = flatten(ctx, idx, n, p, c))) return rcode;
-        std::vector<T> cu, cq;
-        point_coefs(ctx, idx, n, scale, cu, cq);
         const size_t need = (size_t)n * 8 + 16;
         if (ps.cap < need) {
             for (void **q : {&ps.pidx, &ps.cidx, &ps.cu, &ps.cq, &ps.s_pidx, &ps.s_cidx, &ps.s_cu, &ps.s_cq,
@@ -256,6 +248,15 @@ struct Impl {
         };
         HIPCHK(ctx, up(ps.pidx, p.data(), (size_t)n * 8));
         HIPCHK(ctx, up(ps.cidx, c.data(), (size_t)n * 8));
+        // velocities at the points: gathered from the device copy of the model
+        std::vector<T> cpt(n), cu, cq;
+        if (n) {
+            HIPCHK(ctx, launch_record<T>((const T *)ctx->c_dev, (const int64_t *)ps.cidx, (T *)ps.cu, T(1), n,
+                                         ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(cpt.data(), ps.cu, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        point_coefs(ctx, idx, n, scale, cpt, cu, cq);
         HIPCHK(ctx, up(ps.cu, cu.data(), (size_t)n * sizeof(T)));
         HIPCHK(ctx, up(ps.cq, cq.data(), (size_t)n * sizeof(T)));
         std::vector<int> start, col;

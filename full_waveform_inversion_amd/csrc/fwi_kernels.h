@@ -93,6 +93,9 @@ hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipS
 template <typename T>
 hipError_t launch_finalize_gradient(const T *gacc, const T *c, T *out, double scale,
                                     int wrt_velocity, int64_t n, hipStream_t s);
+// Cpad (padded, halo untouched) = dt2 * c^2 from the compact velocity c; *bad += #invalid entries
+template <typename T>
+hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2, int *bad, hipStream_t s);
 // *out += sum a[i] * b[i]  (out must be zeroed by the caller)
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);

@@ -744,6 +744,27 @@ hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipS
     return hipGetLastError();
 }
 
+// padded C = dt^2 c^2 from the compact velocity; counts non-finite / non-positive entries in *bad
+template <typename T>
+__global__ void build_model_kernel(GridDesc g, const T *c, T *Cpad, double dt2, int *bad) {
+    for (int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ci < g.npts;
+         ci += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = ci / g.nx;
+        const int x = (int)(ci - row * g.nx);
+        const int z = (int)(row / g.ny), y = (int)(row % g.ny);
+        const double cv = (double)c[ci];
+        if (!(cv > 0.0) || !isfinite(cv)) atomicAdd(bad, 1);
+        Cpad[g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x] = (T)(dt2 * cv * cv);
+    }
+}
+
+template <typename T>
+hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2, int *bad, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (g.npts + 255) / 256));
+    hipLaunchKernelGGL(build_model_kernel<T>, dim3(blocks), dim3(256), 0, s, g, c, Cpad, dt2, bad);
+    return hipGetLastError();
+}
+
 template <typename T>
 __global__ void finalize_gradient_kernel(const T *gacc, const T *c, T *out, double scale,
                                          int wrt_velocity, int64_t n) {
@@ -795,7 +816,8 @@ hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_
     template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
     template hipError_t launch_finalize_gradient<T>(const T *, const T *, T *, double, int, int64_t, \
                                                     hipStream_t);                                  \
-    template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);
+    template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
+    template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t);
 FWI_INSTANTIATE(float)
 FWI_INSTANTIATE(double)
 
