@@ -17,7 +17,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
     an FWI misfit has no natural scale).  ``dot(a, b)``: inner product (pass ``Engine.dot``
     for the GPU wave-shuffle reduction).  Returns ``(x, f, log)``.
     """
-    dot = dot or (lambda a, b: float(np.vdot(a.astype(np.float64), b.astype(np.float64))))
+    dot = dot or (lambda a, b: float(np.sum(np.multiply(a, b, dtype=np.float64))))  # no BLAS threads
     lo, hi = bounds if bounds is not None else (None, None)
 
     def project(x):
