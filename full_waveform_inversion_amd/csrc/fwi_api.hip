@@ -78,6 +78,8 @@ struct fwi_ctx {
     void *amp = nullptr;     // (nt, nrec) residual being back-propagated
     void *series = nullptr;  // (nt, n) sampled series of the running sweep
     size_t cap_wav = 0, cap_amp = 0, cap_series = 0;
+    void *pin = nullptr;     // pinned host staging for the time series
+    size_t cap_pin = 0;
     // checkpointing (SURVEY s.8f-3): snapshot of (u^n, u^{n-1}) every `ckpt` steps instead of the
     // imaging term of every step; q_store then holds ckpt + 1 slots and fwd[] the recomputed fields
     int ckpt = 0;
@@ -127,6 +129,40 @@ int upload_vec(fwi_ctx *ctx, void *dst, const std::vector<double> &v) {
     std::vector<T> t(v.begin(), v.end());
     HIPCHK(ctx, hipMemcpyAsync(dst, t.data(), t.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+// Time series cross the PCIe boundary through a persistent pinned staging buffer: the caller's
+// NumPy arrays are pageable and usually freshly mapped, and the driver's pageable path cost up to
+// tens of ms per 2 MB copy (measured in the 2-D shot loop).
+int stage_reserve(fwi_ctx *ctx, size_t bytes) {
+    if (ctx->cap_pin >= bytes && ctx->pin) return FWI_OK;
+    if (ctx->pin) HIPCHK(ctx, hipHostFree(ctx->pin));
+    ctx->pin = nullptr;
+    HIPCHK(ctx, hipHostMalloc(&ctx->pin, bytes ? bytes : 16, hipHostMallocDefault));
+    ctx->cap_pin = bytes;
+    return FWI_OK;
+}
+
+int upload_series(fwi_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return FWI_OK;
+    int rc = stage_reserve(ctx, bytes);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
+    memcpy(ctx->pin, src, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(dst, ctx->pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return FWI_OK;
+}
+
+// device -> caller; synchronises the stream
+int download_series(fwi_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes) {
+        int rc = stage_reserve(ctx, bytes);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) memcpy(dst, ctx->pin, bytes);
     return FWI_OK;
 }
 
@@ -402,8 +438,7 @@ struct Impl {
         ctx->have_forward = false;
         ctx->have_q = false;
         hipStream_t s = ctx->stream;
-        if (nsrc)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->wav, wavelet, (size_t)nt * nsrc * sizeof(T), hipMemcpyHostToDevice, s));
+        if (nsrc && (rc = upload_series(ctx, ctx->wav, wavelet, (size_t)nt * nsrc * sizeof(T)))) return rc;
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
         Sweep sw;
         sw.f[0] = ctx->u[0];
@@ -431,10 +466,9 @@ struct Impl {
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
-        if (nrec && seis_out)
-            HIPCHK(ctx, hipMemcpyAsync(seis_out, ctx->series, (size_t)nt * nrec * sizeof(T),
-                                       hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
+        if ((rc = download_series(ctx, seis_out, ctx->series,
+                                  (nrec && seis_out) ? (size_t)nt * nrec * sizeof(T) : 0)))
+            return rc;
         ctx->have_forward = true;
         ctx->have_q = save != 0;
         return FWI_OK;
@@ -445,9 +479,8 @@ struct Impl {
         const int nt = ctx->nt, K = ctx->ckpt;
         hipStream_t s = ctx->stream;
         int rc;
-        if (ctx->nrec)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T),
-                                       hipMemcpyHostToDevice, s));
+        if (ctx->nrec && (rc = upload_series(ctx, ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T))))
+            return rc;
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
         Sweep sw;
@@ -527,11 +560,8 @@ struct Impl {
             HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
-        if (adj_src_out && ctx->nsrc)
-            HIPCHK(ctx, hipMemcpyAsync(adj_src_out, ctx->series, (size_t)nt * ctx->nsrc * sizeof(T),
-                                       hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        return FWI_OK;
+        return download_series(ctx, adj_src_out, ctx->series,
+                               (adj_src_out && ctx->nsrc) ? (size_t)nt * ctx->nsrc * sizeof(T) : 0);
     }
 
     static int gradient(fwi_ctx *ctx, int32_t wrt, T *out) {
@@ -709,6 +739,7 @@ void fwi_destroy(fwi_ctx *ctx) {
             if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
