@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -60,6 +60,16 @@ SIGNATURES = {
     "fwi_synchronize": (C.c_int, [_P]),
     "fwi_kernel_name": (C.c_char_p, [_P]),
     "fwi_device_count": (C.c_int, [C.POINTER(_I32)]),
+    "fwi_vec_create": (C.c_int, [_P, _I32]),
+    "fwi_vec_upload": (C.c_int, [_P, _I32, _P]),
+    "fwi_vec_download": (C.c_int, [_P, _I32, _P]),
+    "fwi_vec_copy": (C.c_int, [_P, _I32, _I32]),
+    "fwi_vec_axpby": (C.c_int, [_P, _I32, _D, _I32, _D]),
+    "fwi_vec_dot": (C.c_int, [_P, _I32, _I32, C.POINTER(_D)]),
+    "fwi_vec_absmax": (C.c_int, [_P, _I32, C.POINTER(_D)]),
+    "fwi_vec_clip": (C.c_int, [_P, _I32, _D, _D]),
+    "fwi_set_model_vec": (C.c_int, [_P, _I32]),
+    "fwi_gradient_vec": (C.c_int, [_P, _I32, _I32]),
     "fwi_mc_score": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P,
                                C.POINTER(_D)]),
     "fwi_mc_forward": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P]),

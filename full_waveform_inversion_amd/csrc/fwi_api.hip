@@ -78,6 +78,7 @@ struct fwi_ctx {
     void *amp = nullptr;     // (nt, nrec) residual being back-propagated
     void *series = nullptr;  // (nt, n) sampled series of the running sweep
     size_t cap_wav = 0, cap_amp = 0, cap_series = 0;
+    std::vector<void *> vecs;  // optimiser vectors (compact, model-sized)
     void *pin = nullptr;     // pinned host staging for the time series
     size_t cap_pin = 0;
     // checkpointing (SURVEY s.8f-3): snapshot of (u^n, u^{n-1}) every `ckpt` steps instead of the
@@ -230,6 +231,18 @@ struct Impl {
         // compact H2D copy, then validation + padded C = dt^2 c^2 on the device (the halo of C
         // was zeroed at creation and is never written)
         HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, c, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice, s));
+        return finish_model(ctx);
+    }
+
+    static int set_model_vec(fwi_ctx *ctx, const void *dev) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, dev, (size_t)ctx->gd.npts * sizeof(T), hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        return finish_model(ctx);
+    }
+
+    static int finish_model(fwi_ctx *ctx) {
+        const GridDesc &g = ctx->gd;
+        hipStream_t s = ctx->stream;
         int *bad = (int *)(ctx->red + 4);
         HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), s));
         HIPCHK(ctx, launch_build_model<T>(g, (const T *)ctx->c_dev, (T *)ctx->C, ctx->cfg.dt * ctx->cfg.dt, bad, s));
@@ -564,6 +577,39 @@ struct Impl {
                                (adj_src_out && ctx->nsrc) ? (size_t)nt * ctx->nsrc * sizeof(T) : 0);
     }
 
+    static int gradient_vec(fwi_ctx *ctx, int32_t wrt, void *dev) {
+        const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
+        HIPCHK(ctx, launch_finalize_gradient<T>((const T *)ctx->g_acc, (const T *)ctx->c_dev, (T *)dev, scale,
+                                                wrt == FWI_WRT_VELOCITY, ctx->gd.npts, ctx->stream));
+        return FWI_OK;
+    }
+
+    static int vec_dot(fwi_ctx *ctx, const void *x, const void *y, double *out) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->red, 0, sizeof(double), ctx->stream));
+        HIPCHK(ctx, launch_dot<T>((const T *)x, (const T *)y, ctx->gd.npts, ctx->red, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return FWI_OK;
+    }
+
+    static int vec_absmax(fwi_ctx *ctx, const void *x, double *out) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->red, 0, sizeof(double), ctx->stream));
+        HIPCHK(ctx, launch_absmax<T>((const T *)x, ctx->gd.npts, ctx->red, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out, ctx->red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return FWI_OK;
+    }
+
+    static int vec_axpby(fwi_ctx *ctx, void *y, double a, const void *x, double b) {
+        HIPCHK(ctx, launch_axpby<T>((T *)y, a, (const T *)x, b, ctx->gd.npts, ctx->stream));
+        return FWI_OK;
+    }
+
+    static int vec_clip(fwi_ctx *ctx, void *x, double lo, double hi) {
+        HIPCHK(ctx, launch_clip<T>((T *)x, lo, hi, ctx->gd.npts, ctx->stream));
+        return FWI_OK;
+    }
+
     static int gradient(fwi_ctx *ctx, int32_t wrt, T *out) {
         const GridDesc &g = ctx->gd;
         const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
@@ -739,6 +785,8 @@ void fwi_destroy(fwi_ctx *ctx) {
             if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *v : ctx->vecs)
+        if (v) (void)hipFree(v);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -813,6 +861,110 @@ int fwi_dot(fwi_ctx *ctx, const void *a, const void *b, int64_t n, double *out) 
     (void)hipSetDevice(ctx->cfg.device);
     return DISPATCH(ctx, Impl<float>::dot(ctx, (const float *)a, (const float *)b, n, out),
                     Impl<double>::dot(ctx, (const double *)a, (const double *)b, n, out));
+}
+
+static void *vec_slot(fwi_ctx *ctx, int32_t slot) {
+    return (slot >= 0 && slot < (int32_t)ctx->vecs.size()) ? ctx->vecs[slot] : nullptr;
+}
+
+#define VEC_OR_FAIL(ctx, name, slot)                                                            \
+    void *name = vec_slot(ctx, slot);                                                           \
+    if (!name) return (ctx)->fail(FWI_EINVAL, "%s: vector slot %d does not exist", __func__, (int)(slot))
+
+int fwi_vec_create(fwi_ctx *ctx, int32_t count) {
+    if (!ctx) return FWI_EINVAL;
+    if (count < 0 || count > 256) return ctx->fail(FWI_EINVAL, "fwi_vec_create: count must be in [0, 256]");
+    (void)hipSetDevice(ctx->cfg.device);
+    for (void *v : ctx->vecs)
+        if (v) (void)hipFree(v);
+    ctx->vecs.assign(count, nullptr);
+    const size_t bytes = (size_t)ctx->gd.npts * ctx->esize;
+    for (int i = 0; i < count; ++i) {
+        HIPCHK(ctx, hipMalloc(&ctx->vecs[i], bytes));
+        HIPCHK(ctx, hipMemsetAsync(ctx->vecs[i], 0, bytes, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_vec_upload(fwi_ctx *ctx, int32_t slot, const void *host) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, v, slot);
+    if (!host) return ctx->fail(FWI_EINVAL, "fwi_vec_upload: null buffer");
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipMemcpyAsync(v, host, (size_t)ctx->gd.npts * ctx->esize, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_vec_download(fwi_ctx *ctx, int32_t slot, void *host) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, v, slot);
+    if (!host) return ctx->fail(FWI_EINVAL, "fwi_vec_download: null buffer");
+    (void)hipSetDevice(ctx->cfg.device);
+    HIPCHK(ctx, hipMemcpyAsync(host, v, (size_t)ctx->gd.npts * ctx->esize, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_vec_copy(fwi_ctx *ctx, int32_t dst, int32_t src) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, d, dst);
+    VEC_OR_FAIL(ctx, s, src);
+    (void)hipSetDevice(ctx->cfg.device);
+    if (d != s)
+        HIPCHK(ctx, hipMemcpyAsync(d, s, (size_t)ctx->gd.npts * ctx->esize, hipMemcpyDeviceToDevice, ctx->stream));
+    return FWI_OK;
+}
+
+int fwi_vec_axpby(fwi_ctx *ctx, int32_t y, double a, int32_t x, double b) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, vy, y);
+    VEC_OR_FAIL(ctx, vx, x);
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::vec_axpby(ctx, vy, a, vx, b), Impl<double>::vec_axpby(ctx, vy, a, vx, b));
+}
+
+int fwi_vec_dot(fwi_ctx *ctx, int32_t x, int32_t y, double *out) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, vx, x);
+    VEC_OR_FAIL(ctx, vy, y);
+    if (!out) return ctx->fail(FWI_EINVAL, "fwi_vec_dot: null output");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::vec_dot(ctx, vx, vy, out), Impl<double>::vec_dot(ctx, vx, vy, out));
+}
+
+int fwi_vec_absmax(fwi_ctx *ctx, int32_t x, double *out) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, vx, x);
+    if (!out) return ctx->fail(FWI_EINVAL, "fwi_vec_absmax: null output");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::vec_absmax(ctx, vx, out), Impl<double>::vec_absmax(ctx, vx, out));
+}
+
+int fwi_vec_clip(fwi_ctx *ctx, int32_t x, double lo, double hi) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, vx, x);
+    if (!(lo <= hi)) return ctx->fail(FWI_EINVAL, "fwi_vec_clip: lo > hi");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::vec_clip(ctx, vx, lo, hi), Impl<double>::vec_clip(ctx, vx, lo, hi));
+}
+
+int fwi_set_model_vec(fwi_ctx *ctx, int32_t slot) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, v, slot);
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::set_model_vec(ctx, v), Impl<double>::set_model_vec(ctx, v));
+}
+
+int fwi_gradient_vec(fwi_ctx *ctx, int32_t wrt, int32_t slot) {
+    if (!ctx) return FWI_EINVAL;
+    VEC_OR_FAIL(ctx, v, slot);
+    if (wrt != FWI_WRT_VELOCITY && wrt != FWI_WRT_SLOWNESS2)
+        return ctx->fail(FWI_EINVAL, "fwi_gradient_vec: unknown parametrisation %d", wrt);
+    if (!ctx->have_model) return ctx->fail(FWI_ESTATE, "fwi_gradient_vec: no model set");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::gradient_vec(ctx, wrt, v), Impl<double>::gradient_vec(ctx, wrt, v));
 }
 
 int fwi_comm_unique_id(void *id_out) {

@@ -100,4 +100,12 @@ hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);
 
+// optimiser vector algebra: y = a x + b y; clamp; *out = max(*out, max|x|) (out zeroed by the caller)
+template <typename T>
+hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStream_t s);
+template <typename T>
+hipError_t launch_clip(T *x, double lo, double hi, int64_t n, hipStream_t s);
+template <typename T>
+hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s);
+
 }  // namespace fwi

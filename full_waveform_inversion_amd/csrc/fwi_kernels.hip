@@ -811,13 +811,65 @@ hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_
     return hipGetLastError();
 }
 
+// Model-sized vector algebra for the optimiser (device-resident L-BFGS state).
+template <typename T>
+__global__ void axpby_kernel(T *y, double a, const T *x, double b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = (T)(a * (double)x[i] + b * (double)y[i]);
+}
+
+template <typename T>
+__global__ void clip_kernel(T *x, double lo, double hi, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = (T)fmin(fmax((double)x[i], lo), hi);
+}
+
+// *out = max(*out, max |x|): wave64 shuffle max, LDS across waves, one atomic per block.  The
+// bit pattern of a non-negative double orders like an unsigned integer.
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T *x, int64_t n, unsigned long long *out) {
+    double m = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, fabs((double)x[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+static inline int vec_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n + 255) / 256)); }
+
+template <typename T>
+hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpby_kernel<T>, dim3(vec_blocks(n)), dim3(256), 0, s, y, a, x, b, n);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_clip(T *x, double lo, double hi, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(clip_kernel<T>, dim3(vec_blocks(n)), dim3(256), 0, s, x, lo, hi, n);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_kernel<T>, dim3(vec_blocks(n)), dim3(256), 0, s, x, n, (unsigned long long *)out);
+    return hipGetLastError();
+}
+
 #define FWI_INSTANTIATE(T)                                                                          \
     template hipError_t launch_record<T>(const T *, const int64_t *, T *, T, int, hipStream_t);    \
     template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
     template hipError_t launch_finalize_gradient<T>(const T *, const T *, T *, double, int, int64_t, \
                                                     hipStream_t);                                  \
     template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
-    template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t);
+    template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t); \
+    template hipError_t launch_axpby<T>(T *, double, const T *, double, int64_t, hipStream_t);         \
+    template hipError_t launch_clip<T>(T *, double, double, int64_t, hipStream_t);                    \
+    template hipError_t launch_absmax<T>(const T *, int64_t, double *, hipStream_t);
 FWI_INSTANTIATE(float)
 FWI_INSTANTIATE(double)
 

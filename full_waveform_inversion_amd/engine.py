@@ -195,6 +195,46 @@ class Engine:
         self._chk(self._lib.fwi_allreduce_f64(self._ctx, arr, len(vals)))
         return list(arr)
 
+    # -- device-resident model-shaped vectors (optimiser state) ------------------------
+    def vec_create(self, count):
+        self._chk(self._lib.fwi_vec_create(self._ctx, int(count)))
+
+    def vec_upload(self, slot, a):
+        a = self._host(a, self.shape)
+        self._chk(self._lib.fwi_vec_upload(self._ctx, slot, a.ctypes.data_as(C.c_void_p)))
+
+    def vec_download(self, slot):
+        out = np.empty(self.shape, self.dtype)
+        self._chk(self._lib.fwi_vec_download(self._ctx, slot, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def vec_copy(self, dst, src):
+        self._chk(self._lib.fwi_vec_copy(self._ctx, dst, src))
+
+    def vec_axpby(self, y, a, x, b=1.0):
+        """y = a * x + b * y on the device."""
+        self._chk(self._lib.fwi_vec_axpby(self._ctx, y, float(a), x, float(b)))
+
+    def vec_dot(self, x, y):
+        out = C.c_double(0.0)
+        self._chk(self._lib.fwi_vec_dot(self._ctx, x, y, C.byref(out)))
+        return out.value
+
+    def vec_absmax(self, x):
+        out = C.c_double(0.0)
+        self._chk(self._lib.fwi_vec_absmax(self._ctx, x, C.byref(out)))
+        return out.value
+
+    def vec_clip(self, x, lo, hi):
+        self._chk(self._lib.fwi_vec_clip(self._ctx, x, float(lo), float(hi)))
+
+    def set_model_vec(self, slot):
+        self._chk(self._lib.fwi_set_model_vec(self._ctx, slot))
+
+    def gradient_vec(self, slot, wrt="velocity"):
+        w = {"velocity": _lib.WRT_VELOCITY, "slowness2": _lib.WRT_SLOWNESS2}[wrt]
+        self._chk(self._lib.fwi_gradient_vec(self._ctx, w, slot))
+
     def last_loop_ms(self):
         ms = C.c_double(0.0)
         self._chk(self._lib.fwi_last_loop_ms(self._ctx, C.byref(ms)))

@@ -74,3 +74,87 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         if callback:
             callback(it, x, f, g)
     return x, f, log
+
+
+def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=None, c1=1e-4, max_ls=8,
+                 gtol=0.0, callback=None):
+    """The same iteration as :func:`lbfgs` with every model-sized vector resident on the GPU
+    (``Engine.vec_*`` slots): per iteration only scalars cross PCIe.
+
+    ``fg(x_slot, g_slot) -> f`` evaluates the misfit at the model in ``x_slot`` and leaves the
+    gradient in ``g_slot`` (see ``shots.misfit_and_gradient_device``).  Returns ``(x, f, log)``
+    with ``x`` downloaded once at the end.
+    """
+    m = int(history)
+    X, G, XN, GN, P = 0, 1, 2, 3, 4
+    S0, Y0 = 5, 5 + m
+    engine.vec_create(5 + 2 * m)
+    engine.vec_upload(X, x0)
+    if bounds is not None:
+        engine.vec_clip(X, *bounds)
+    f = fg(X, G)
+    pairs = []  # ring of (s_slot, y_slot), oldest first
+    free = list(range(m))
+    log = [{"iter": 0, "f": f, "evals": 1}]
+    evals = 1
+    for it in range(1, maxiter + 1):
+        gmax = engine.vec_absmax(G)
+        if not gmax > gtol:
+            break
+        engine.vec_copy(P, G)  # P holds q; the search direction is -P
+        al = []
+        for s, y in reversed(pairs):
+            rho = 1.0 / engine.vec_dot(y, s)
+            a = rho * engine.vec_dot(s, P)
+            engine.vec_axpby(P, -a, y, 1.0)
+            al.append((a, rho))
+        if pairs:
+            s, y = pairs[-1]
+            engine.vec_axpby(P, 0.0, P, engine.vec_dot(s, y) / engine.vec_dot(y, y))
+        else:
+            engine.vec_axpby(P, 0.0, P, (first_step if first_step is not None else 1.0) / gmax)
+        for (s, y), (a, rho) in zip(pairs, reversed(al)):
+            b = rho * engine.vec_dot(y, P)
+            engine.vec_axpby(P, a - b, s, 1.0)
+        gp = -engine.vec_dot(G, P)
+        if not gp < 0.0:  # not a descent direction: restart from steepest descent
+            free += [s - S0 for s, _ in pairs]
+            pairs = []
+            engine.vec_copy(P, G)
+            engine.vec_axpby(P, 0.0, P, (first_step if first_step is not None else 1.0) / gmax)
+            gp = -engine.vec_dot(G, P)
+        t = 1.0
+        for _ in range(max_ls):
+            engine.vec_copy(XN, X)
+            engine.vec_axpby(XN, -t, P, 1.0)
+            if bounds is not None:
+                engine.vec_clip(XN, *bounds)
+            fn = fg(XN, GN)
+            evals += 1
+            if fn <= f + c1 * t * gp:
+                break
+            t *= 0.5
+        else:
+            log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
+            break
+        if not free:  # drop the oldest pair
+            s_old, _ = pairs.pop(0)
+            free.append(s_old - S0)
+        k = free.pop(0)
+        s, y = S0 + k, Y0 + k
+        engine.vec_copy(s, XN)
+        engine.vec_axpby(s, -1.0, X, 1.0)
+        engine.vec_copy(y, GN)
+        engine.vec_axpby(y, -1.0, G, 1.0)
+        sy = engine.vec_dot(s, y)
+        if sy > 1e-12 * np.sqrt(engine.vec_dot(s, s) * engine.vec_dot(y, y)):
+            pairs.append((s, y))
+        else:
+            free.append(k)
+        X, XN = XN, X
+        G, GN = GN, G
+        f = fn
+        log.append({"iter": it, "f": f, "evals": evals, "step": t})
+        if callback:
+            callback(it, X, f, G)
+    return engine.vec_download(X), f, log

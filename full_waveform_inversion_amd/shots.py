@@ -36,6 +36,9 @@ class NoExchange:
     def reduce(self, engine, misfit, wrt):
         return engine.gradient(wrt), misfit
 
+    def reduce_device(self, engine, misfit):
+        return misfit
+
 
 class RcclExchange:
     """Production exchange: RCCL all-reduce (over xGMI) of the device-side accumulators.
@@ -52,6 +55,11 @@ class RcclExchange:
     def reduce(self, engine, misfit, wrt):
         engine.allreduce_gradient()
         return engine.gradient(wrt), engine.allreduce_f64([misfit])[0]
+
+    def reduce_device(self, engine, misfit):
+        """Sum the device-side accumulators only; the gradient stays on the GPU."""
+        engine.allreduce_gradient()
+        return engine.allreduce_f64([misfit])[0]
 
 
 class HostExchange:
@@ -103,3 +111,26 @@ def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", obj
         misfit += j
         engine.adjoint(r)
     return ex.reduce(engine, misfit, wrt)[::-1]
+
+
+def misfit_and_gradient_device(engine, model_slot, grad_slot, shots, exchange=None, wrt="velocity",
+                               objective=None):
+    """Like :func:`misfit_and_gradient`, with the model read from and the gradient written to
+    device-resident vectors (``Engine.vec_*``): no model-sized array crosses PCIe."""
+    from .objectives import l2
+    objective = objective or l2
+    ex = exchange or NoExchange()
+    engine.set_model_vec(model_slot)
+    engine.reset_gradient()
+    misfit = 0.0
+    for i in partition_shots(len(shots), ex.rank, ex.world):
+        s = shots[i]
+        if s.d_obs is None:
+            raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
+        d = engine.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
+        j, r = objective(d, s.d_obs)
+        misfit += j
+        engine.adjoint(r)
+    misfit = ex.reduce_device(engine, misfit)
+    engine.gradient_vec(grad_slot, wrt)
+    return misfit

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 3
+#define FWI_ABI_VERSION 4
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -121,6 +121,22 @@ int fwi_gradient_reset(fwi_ctx *ctx);
  * sum_i a[i]*b[i] over n host elements of the context dtype, wave-shuffle
  * reduced on the GPU, fp64 accumulate.  [SURVEY s.8(a-1) row dot-products] */
 int fwi_dot(fwi_ctx *ctx, const void *a_host, const void *b_host, int64_t n, double *out);
+
+/* Device-resident, model-shaped vectors for the optimiser (L-BFGS history, search direction,
+ * trial model): `count` slots owned by the context; all algebra runs on the GPU so an iteration
+ * moves no model-sized array over PCIe.  [SURVEY s.8(a-1) rows L-BFGS / dot-products] */
+int fwi_vec_create(fwi_ctx *ctx, int32_t count);
+int fwi_vec_upload(fwi_ctx *ctx, int32_t slot, const void *host);
+int fwi_vec_download(fwi_ctx *ctx, int32_t slot, void *host);
+int fwi_vec_copy(fwi_ctx *ctx, int32_t dst, int32_t src);
+int fwi_vec_axpby(fwi_ctx *ctx, int32_t y, double a, int32_t x, double b); /* y = a x + b y */
+int fwi_vec_dot(fwi_ctx *ctx, int32_t x, int32_t y, double *out);
+int fwi_vec_absmax(fwi_ctx *ctx, int32_t x, double *out);
+int fwi_vec_clip(fwi_ctx *ctx, int32_t x, double lo, double hi);
+/* model := slot (velocity), without leaving the device */
+int fwi_set_model_vec(fwi_ctx *ctx, int32_t slot);
+/* slot := accumulated gradient (after fwi_allreduce_gradient, if any), as fwi_gradient() */
+int fwi_gradient_vec(fwi_ctx *ctx, int32_t wrt, int32_t slot);
 
 /* Shot-parallel exchange: one RCCL communicator per context, sum of the
  * gradient accumulators over ranks (in place, on device).  The reference's

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 from full_waveform_inversion_amd import Engine, shots as sh, workloads  # noqa: E402
-from full_waveform_inversion_amd.lbfgs import lbfgs  # noqa: E402
+from full_waveform_inversion_amd.lbfgs import lbfgs, lbfgs_device  # noqa: E402
 
 
 def main():
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--shots", type=int, default=0, help="0 = the config's own count (32 / 64)")
     ap.add_argument("--iters", type=int, default=0, help="L-BFGS iterations; 0 = one gradient only")
+    ap.add_argument("--host-lbfgs", action="store_true", help="keep the optimiser vectors on the host")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -54,9 +55,16 @@ def main():
         return sh.misfit_and_gradient(e, m, shots, ex)
 
     m0 = w.c_init.astype(np.float32)
-    if a.iters > 0:
+    bounds = (0.5 * float(w.c.min()), 1.5 * float(w.c.max()))
+    if a.iters > 0 and not a.host_lbfgs:
+        def fg_dev(xs, gs):
+            evals[0] += 1
+            return sh.misfit_and_gradient_device(e, xs, gs, shots, ex)
+        _, _, log = lbfgs_device(e, fg_dev, m0, maxiter=a.iters, history=5, first_step=0.02 * float(m0.max()),
+                                 bounds=bounds)
+    elif a.iters > 0:
         _, _, log = lbfgs(fg, m0, maxiter=a.iters, history=5, first_step=0.02 * float(m0.max()),
-                          bounds=(0.5 * float(w.c.min()), 1.5 * float(w.c.max())), dot=e.dot)
+                          bounds=bounds, dot=e.dot)
     else:
         J, g = fg(m0)
         log = [{"iter": 0, "f": J, "gnorm": float(np.sqrt(e.dot(g, g)))}]
