@@ -380,3 +380,15 @@ def test_device_lbfgs_matches_host_lbfgs(gpu):
     assert [r["evals"] for r in logd] == [r["evals"] for r in logh]
     assert abs(fd - fh) < 1e-3 * fh and fd < 0.6 * logd[0]["f"]
     assert rel(xd, xh) < 1e-5
+
+
+def test_store_too_large_is_a_clean_error(gpu):
+    """A forward-term store that cannot fit must fail with FWI_ENOMEM and a usable message."""
+    n = 512
+    with Engine((n, n, n), 10.0, 1e-3, 100000, npml=0) as e:  # 100000 x 512^3 x 4 B = 50 TB
+        e.set_model(np.full((n, n, n), 2000.0, np.float32))
+        with pytest.raises(FwiError) as ei:
+            e.forward(None, ([[8, 8, 8]], np.ones(4, np.float32)), [[9, 9, 9]], save=True)
+        assert ei.value.code == 4 and "ckpt_interval" in str(ei.value)
+        d = e.forward(None, ([[8, 8, 8]], np.ones(4, np.float32)), [[9, 9, 9]], save=False)  # still usable
+        assert d.shape == (4, 1)
