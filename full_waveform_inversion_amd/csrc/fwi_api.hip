@@ -42,7 +42,7 @@ struct fwi_ctx {
     fwi_config cfg;
     GridDesc gd;
     int kernel = K_POINT;
-    StreamTuning tune{8, 0, 1};
+    StreamTuning tune{8, 0, 1, 256};
     size_t esize = 4;  // bytes per element
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -746,11 +746,11 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
-        return bad("STREAM kernel needs an fp32 grid with nx % 4 == 0");
+        return bad("STREAM kernel needs nx % 4 == 0 (fp32) or a 3-D grid with nx % 2 == 0 (fp64)");
     }
     ctx->kernel = (cfg->kernel == FWI_KERNEL_POINT || !can_stream) ? K_POINT : K_STREAM;
     if (ctx->kernel == K_STREAM) {
-        ctx->tune = stream_default_tuning(ctx->gd);
+        ctx->tune = stream_default_tuning(ctx->gd, cfg->dtype == FWI_F32);
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
         if (const char *pf = getenv("FWI_STREAM_PF")) {  // tuning hook: prefetch depth in planes
             const int v = atoi(pf);

@@ -64,6 +64,7 @@ struct StreamTuning {
     int ty;      // rows per workgroup (4 or 8)
     int zchunk;  // planes marched per workgroup
     int pf;      // planes fetched ahead of use (1..3)
+    int tile_x;  // x extent of a tile in elements: 64 lanes x one 16-byte vector (256 fp32 / 128 fp64)
 };
 
 // Workgroup tile of the stream kernel that owns grid point (z, y, x): the index
@@ -77,7 +78,7 @@ int point_num_tiles(const GridDesc &g);
 
 // True when the stream kernel supports this grid / dtype.
 bool stream_supported(const GridDesc &g, bool is_f32);
-StreamTuning stream_default_tuning(const GridDesc &g);
+StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32);
 
 template <typename T>
 hipError_t launch_step(int kernel, const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t,

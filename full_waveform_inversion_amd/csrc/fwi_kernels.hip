@@ -122,28 +122,51 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
 // traffic.  Blocks are renumbered so each XCD (private 4 MiB L2) owns a
 // contiguous slab of tiles and shares those halo rows on chip.
 // ---------------------------------------------------------------------------
-struct alignas(16) f4 {
-    float v[4];
+// 16-byte vector of the field type: float4 / double2.  One per lane = 1 KiB per wave-instruction.
+template <typename T> struct VecOf;
+template <> struct VecOf<float> {
+    static constexpr int VL = 4;
+    typedef float nt_t __attribute__((ext_vector_type(4)));
 };
+template <> struct VecOf<double> {
+    static constexpr int VL = 2;
+    typedef double nt_t __attribute__((ext_vector_type(2)));
+};
+template <typename T>
+struct alignas(16) vec {
+    T v[VecOf<T>::VL];
+};
+using f4 = vec<float>;
 
-__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
-__device__ __forceinline__ void st4(float *p, const f4 &v) { *reinterpret_cast<f4 *>(p) = v; }
+template <typename T>
+__device__ __forceinline__ vec<T> ldv(const T *p) { return *reinterpret_cast<const vec<T> *>(p); }
+template <typename T>
+__device__ __forceinline__ void stv(T *p, const vec<T> &v) { *reinterpret_cast<vec<T> *>(p) = v; }
 
 // Streaming (non-temporal) forms for the once-per-step traffic of the imaging term q: it is
 // written once in the forward pass and read once in the adjoint pass, tens of GiB per shot, and
 // must not evict the wavefields from L2 / Infinity Cache.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 ld4_stream(const float *p) {
-    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-    f4 r;
-    r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+template <typename T>
+__device__ __forceinline__ vec<T> ldv_stream(const T *p) {
+    typedef typename VecOf<T>::nt_t nt_t;
+    const nt_t v = __builtin_nontemporal_load(reinterpret_cast<const nt_t *>(p));
+    vec<T> r;
+#pragma unroll
+    for (int j = 0; j < VecOf<T>::VL; ++j) r.v[j] = v[j];
     return r;
 }
-__device__ __forceinline__ void st4_stream(float *p, const f4 &f) {
-    v4f v;
-    v.x = f.v[0]; v.y = f.v[1]; v.z = f.v[2]; v.w = f.v[3];
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+template <typename T>
+__device__ __forceinline__ void stv_stream(T *p, const vec<T> &f) {
+    typedef typename VecOf<T>::nt_t nt_t;
+    nt_t v;
+#pragma unroll
+    for (int j = 0; j < VecOf<T>::VL; ++j) v[j] = f.v[j];
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_t *>(p));
 }
+__device__ __forceinline__ f4 ld4(const float *p) { return ldv<float>(p); }
+__device__ __forceinline__ void st4(float *p, const f4 &v) { stv<float>(p, v); }
+__device__ __forceinline__ f4 ld4_stream(const float *p) { return ldv_stream<float>(p); }
+__device__ __forceinline__ void st4_stream(float *p, const f4 &v) { stv_stream<float>(p, v); }
 
 // 1 / a for a in [1, 2): hardware reciprocal (1 ulp) + one Newton step, ~0.5 ulp; replaces the
 // ~12-instruction IEEE division in the damping factor A = 1 / (1 + d).
@@ -151,19 +174,25 @@ __device__ __forceinline__ float rcp_nr(float a) {
     const float r = __builtin_amdgcn_rcpf(a);
     return r * fmaf(-a, r, 2.f);
 }
+__device__ __forceinline__ double rcp_nr(double a) { return 1.0 / a; }
 
-constexpr int TILE_X = 256;                // floats per tile row = 64 lanes x float4
-constexpr int LROW4 = TILE_X / 4 + 2;      // LDS row in float4: [left edge][64][right edge]
+constexpr int TILE_X = 256;                // 2-D tile kernel: floats per tile row = 64 lanes x float4
+constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge][64][right edge]
 
 // IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
-template <int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
-__global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, GridDesc g, int zchunk,
+template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
+__global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
     constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
     constexpr int LROWS = TY + 2 * R + 1;
-    __shared__ f4 lds[2][LROWS][LROW4];
+    constexpr int VL = VecOf<T>::VL;       // elements per lane: float4 / double2
+    constexpr int HV = HALO / VL;          // vectors per x-halo side (1 / 2)
+    constexpr int TX = 64 * VL;            // tile row in elements (256 / 128)
+    constexpr int LROWV = 64 + 2 * HV;     // LDS row in vectors: [left edge][64 lanes][right edge]
+    using V = vec<T>;
+    __shared__ V lds[2][LROWS][LROWV];
 
     const int lane = threadIdx.x, ty = threadIdx.y;
     int bid = blockIdx.x;
@@ -179,7 +208,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     const int bx = bid % nxt;
     const int t2 = bid / nxt;
     const int by = t2 % nyt, bz = t2 / nyt;
-    const int x0 = bx * TILE_X + 4 * lane;
+    const int x0 = bx * TX + VL * lane;
     const int y0 = by * TY, y = y0 + ty;
     const int z0 = bz * zchunk;
     const int z1 = min(g.nz, z0 + zchunk);
@@ -209,23 +238,23 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
         hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
         hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + x0);
     }
-    // x edges: lanes 0-3 fetch the 4 floats left of the tile row, lanes 60-63
-    // the 4 floats right of it (one dword each).
-    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TILE_X);
-    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
+    // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
+    // the 4 elements right of it (one scalar load each).
+    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TX);
+    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : poff;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
-    const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : 4 + 4 * lane;
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : (HV + lane) * VL;
 
     // loop-invariant xy part of the damping
-    f4 Axy, Bxy, dxy;
+    V Axy, Bxy, dxy;
     if (DAMP) {
-        const float dyv = (y < g.ny) ? a.dy[y] : 0.f;
+        const T dyv = (y < g.ny) ? a.dy[y] : T(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = dyv + ((x0 + j < g.nx) ? a.dx[x0 + j] : 0.f);
+        for (int j = 0; j < VL; ++j) {
+            const T d = dyv + ((x0 + j < g.nx) ? a.dx[x0 + j] : T(0));
             dxy.v[j] = d;
-            Bxy.v[j] = 1.f - d;
-            Axy.v[j] = rcp_nr(1.f + d);
+            Bxy.v[j] = T(1) - d;
+            Axy.v[j] = rcp_nr(T(1) + d);
         }
     }
 
@@ -244,23 +273,23 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
     constexpr int NQ = (2 * R + 1 + PF + NR - 1) / NR * NR;
     constexpr int HPF = (NQ % (R + 1) == 0) ? R : PF;  // halo prefetch distance
     constexpr int NRH = HPF + 1;
-    f4 zq[NQ];
+    V zq[NQ];
 #pragma unroll
-    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ld4(a.u_cur + (int64_t)min(z0 - R + k, zlast) * sz + poff);
-    f4 up[NR], Cc[NR], halo[NRH][NH];
-    float edge[NR];
+    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)min(z0 - R + k, zlast) * sz + poff);
+    V up[NR], Cc[NR], halo[NRH][NH];
+    T edge[NR];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
-        up[p] = ld4(a.u_prev + o + poff);
-        Cc[p] = ld4(a.C + o + poff);
+        up[p] = ldv<T>(a.u_prev + o + poff);
+        Cc[p] = ldv<T>(a.C + o + poff);
         edge[p] = a.u_cur[o + eoff];
     }
 #pragma unroll
     for (int p = 0; p < HPF; ++p) {
         const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) halo[p][i] = ld4(a.u_cur + o + hoff[i]);
+        for (int i = 0; i < NH; ++i) halo[p][i] = ldv<T>(a.u_cur + o + hoff[i]);
     }
 
     for (int zb = z0; zb < z1; zb += NQ) {
@@ -270,96 +299,101 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
             if (z >= z1) break;
             const int cur = ph % NR, nxt = (ph + PF) % NR;  // NQ % NR == 0: static across blocks
             // slot of plane z - R + k is (ph + k) % NQ
-            const f4 &ctr = zq[(ph + R) % NQ];
+            const V &ctr = zq[(ph + R) % NQ];
 
             // stage the plane's rows in LDS (double buffered: one barrier per plane)
-            f4(*L)[LROW4] = lds[z & 1];
-            L[R + ty][1 + lane] = ctr;
+            V(*L)[LROWV] = lds[z & 1];
+            L[R + ty][HV + lane] = ctr;
 #pragma unroll
-            for (int i = 0; i < NH; ++i) L[hrow[i]][1 + lane] = halo[ph % NRH][i];
-            reinterpret_cast<float *>(&L[erow][0])[ecol] = edge[cur];
+            for (int i = 0; i < NH; ++i) L[hrow[i]][HV + lane] = halo[ph % NRH][i];
+            reinterpret_cast<T *>(&L[erow][0])[ecol] = edge[cur];
 
             // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
             const int64_t on = (int64_t)min(z + PF, zlast) * sz;
-            zq[(ph + 2 * R + PF) % NQ] = ld4(a.u_cur + (int64_t)min(z + R + PF, zlast) * sz + poff);
+            zq[(ph + 2 * R + PF) % NQ] = ldv<T>(a.u_cur + (int64_t)min(z + R + PF, zlast) * sz + poff);
             {
                 const int64_t oh = (int64_t)min(z + HPF, zlast) * sz;
 #pragma unroll
-                for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ld4(a.u_cur + oh + hoff[i]);
+                for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ldv<T>(a.u_cur + oh + hoff[i]);
             }
             edge[nxt] = a.u_cur[on + eoff];
             // (plain loads: non-temporal hints on these read-once streams were measured and
             // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
-            up[nxt] = ld4(a.u_prev + on + poff);
-            Cc[nxt] = ld4(a.C + on + poff);
-            f4 qi, qi2, gi;
+            up[nxt] = ldv<T>(a.u_prev + on + poff);
+            Cc[nxt] = ldv<T>(a.C + on + poff);
+            V qi, qi2, gi;
             if (IMAGE) {
                 const unsigned co = act ? coff : 0u;
-                qi = ld4_stream(a.q_in + (int64_t)z * cplane + co);
-                if (IMAGE == 2) qi2 = ld4_stream(a.q_in2 + (int64_t)z * cplane + co);
-                gi = ld4(a.g + (int64_t)z * cplane + co);
+                qi = ldv_stream<T>(a.q_in + (int64_t)z * cplane + co);
+                if (IMAGE == 2) qi2 = ldv_stream<T>(a.q_in2 + (int64_t)z * cplane + co);
+                gi = ldv<T>(a.g + (int64_t)z * cplane + co);
             }
             __syncthreads();
 
-            const f4 xl = L[R + ty][lane], xr = L[R + ty][lane + 2];
-            float X[12];
+            // X = the HALO elements left of this lane's vector, the vector, the HALO right of it
+            T X[2 * HALO + VL];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                X[j] = xl.v[j];
-                X[4 + j] = ctr.v[j];
-                X[8 + j] = xr.v[j];
+            for (int h = 0; h < HV; ++h) {
+                const V xl = L[R + ty][lane + h], xr = L[R + ty][HV + lane + 1 + h];
+#pragma unroll
+                for (int j = 0; j < VL; ++j) {
+                    X[h * VL + j] = xl.v[j];
+                    X[HALO + VL + h * VL + j] = xr.v[j];
+                }
             }
-            f4 lap;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lap.v[j] = 0.f;
+            for (int j = 0; j < VL; ++j) X[HALO + j] = ctr.v[j];
+            V lap;
+#pragma unroll
+            for (int j = 0; j < VL; ++j) lap.v[j] = T(0);
 #pragma unroll
             for (int k = R; k >= 1; --k) {
-                const f4 ym = L[R + ty - k][1 + lane], yp = L[R + ty + k][1 + lane];
-                const f4 &zm = zq[(ph + R - k) % NQ], &zp = zq[(ph + R + k) % NQ];
-                const float c = a.ck[k];
+                const V ym = L[R + ty - k][HV + lane], yp = L[R + ty + k][HV + lane];
+                const V &zm = zq[(ph + R - k) % NQ], &zp = zq[(ph + R + k) % NQ];
+                const T c = a.ck[k];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = (X[4 + j - k] + X[4 + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
-                    t = fmaf(-6.f, X[4 + j], t);
-                    lap.v[j] = fmaf(c, t, lap.v[j]);
+                for (int j = 0; j < VL; ++j) {
+                    T t = (X[HALO + j - k] + X[HALO + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
+                    t = fma(T(-6), X[HALO + j], t);
+                    lap.v[j] = fma(c, t, lap.v[j]);
                 }
             }
 
-            f4 A = Axy, B = Bxy;
+            V A = Axy, B = Bxy;
             if (DAMP) {
                 // d_z(z) from the plane index: a load here would be a VECTOR load (the compiler
                 // cannot prove the profile is not aliased by the u_next stores) whose wait
                 // drains every prefetch in flight
                 const int dist = max(0, max(a.npml - z, z - (g.nz - 1 - a.npml)));
                 if (dist != 0) {
-                    const float dzv = a.dz_scale * (float)(dist * dist);
+                    const T dzv = a.dz_scale * (T)(dist * dist);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float d = dxy.v[j] + dzv;
-                        B.v[j] = 1.f - d;
-                        A.v[j] = rcp_nr(1.f + d);
+                    for (int j = 0; j < VL; ++j) {
+                        const T d = dxy.v[j] + dzv;
+                        B.v[j] = T(1) - d;
+                        A.v[j] = rcp_nr(T(1) + d);
                     }
                 }
             }
-            f4 q, un;
+            V q, un;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < VL; ++j) {
                 q.v[j] = Cc[cur].v[j] * lap.v[j];
                 if (DAMP)
-                    un.v[j] = (fmaf(2.f, X[4 + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
+                    un.v[j] = (fma(T(2), X[HALO + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
                 else
-                    un.v[j] = (2.f * X[4 + j] - up[cur].v[j]) + q.v[j];
+                    un.v[j] = (T(2) * X[HALO + j] - up[cur].v[j]) + q.v[j];
             }
             if (act) {
-                st4(a.u_prev + (int64_t)z * sz + poff, un);
-                if (SAVE_Q) st4_stream(a.q_out + (int64_t)z * cplane + coff, q);
+                stv<T>(a.u_prev + (int64_t)z * sz + poff, un);
+                if (SAVE_Q) stv_stream<T>(a.q_out + (int64_t)z * cplane + coff, q);
                 if (IMAGE) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        gi.v[j] = fmaf(X[4 + j], qi.v[j], gi.v[j]);
-                        if (IMAGE == 2) gi.v[j] = fmaf(up[cur].v[j], qi2.v[j], gi.v[j]);
+                    for (int j = 0; j < VL; ++j) {
+                        gi.v[j] = fma(X[HALO + j], qi.v[j], gi.v[j]);
+                        if (IMAGE == 2) gi.v[j] = fma(up[cur].v[j], qi2.v[j], gi.v[j]);
                     }
-                    st4(a.g + (int64_t)z * cplane + coff, gi);
+                    stv<T>(a.g + (int64_t)z * cplane + coff, gi);
                 }
             }
         }
@@ -373,7 +407,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<float> a, Grid
         if (s1 > s0) {
             __syncthreads();
             for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
-                const float amp = a.inj_amp[a.inj_col[i]];
+                const T amp = a.inj_amp[a.inj_col[i]];
                 atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
                 if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
             }
@@ -506,45 +540,51 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     }
 }
 
-static inline int stream_nxt(const GridDesc &g) { return (int)(round_up(g.nx, TILE_X) / TILE_X); }
+// x tiles of `tile_x` elements: 64 lanes x one 16-byte vector (256 floats / 128 doubles)
+static inline int stream_nxt(const GridDesc &g, int tile_x) { return (int)(round_up(g.nx, tile_x) / tile_x); }
 
 int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x) {
-    if (g.ndim == 2) return (z / t.ty) * stream_nxt(g) + x / TILE_X;
-    const int nxt = stream_nxt(g), nyt = (g.ny + t.ty - 1) / t.ty;
-    return ((z / t.zchunk) * nyt + y / t.ty) * nxt + x / TILE_X;
+    const int nxt = stream_nxt(g, t.tile_x);
+    if (g.ndim == 2) return (z / t.ty) * nxt + x / t.tile_x;
+    const int nyt = (g.ny + t.ty - 1) / t.ty;
+    return ((z / t.zchunk) * nyt + y / t.ty) * nxt + x / t.tile_x;
 }
 
 int stream_num_tiles(const GridDesc &g, const StreamTuning &t) {
-    if (g.ndim == 2) return stream_nxt(g) * ((g.nz + t.ty - 1) / t.ty);
-    return stream_nxt(g) * ((g.ny + t.ty - 1) / t.ty) * ((g.nz + t.zchunk - 1) / t.zchunk);
+    const int nxt = stream_nxt(g, t.tile_x);
+    if (g.ndim == 2) return nxt * ((g.nz + t.ty - 1) / t.ty);
+    return nxt * ((g.ny + t.ty - 1) / t.ty) * ((g.nz + t.zchunk - 1) / t.zchunk);
 }
 
 bool stream_supported(const GridDesc &g, bool is_f32) {
-    return is_f32 && (g.nx % 4 == 0) && g.nz >= 1;
+    if (g.nz < 1) return false;
+    if (is_f32) return g.nx % 4 == 0;         // float4 lanes (3-D stream kernel, 2-D tile kernel)
+    return g.ndim == 3 && g.nx % 2 == 0;      // double2 lanes: 3-D stream kernel only
 }
 
-StreamTuning stream_default_tuning(const GridDesc &g) {
-    if (g.ndim == 2) return StreamTuning{16, 1, 1};  // rows per workgroup (measured best of 4/8/16); no marching axis
+StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
+    const int tile_x = is_f32 ? 256 : 128;
+    if (g.ndim == 2) return StreamTuning{16, 1, 1, tile_x};  // rows per workgroup (best of 4/8/16); no marching axis
     // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
     // (about one per CU, 256 CUs) each marching as many planes as possible, because every
     // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
     // (256 workgroups) 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256 328 vs TY 4 x 256 302
     // (8 rows per tile halve the y-halo re-read once the z chunks are long anyway).
-    StreamTuning best{4, g.nz, 1};
+    StreamTuning best{4, g.nz, 1, tile_x};
     for (int ty : {8, 4}) {
-        const int64_t tiles_xy = stream_nxt(g) * (round_up(g.ny, ty) / ty);
+        const int64_t tiles_xy = stream_nxt(g, tile_x) * (round_up(g.ny, ty) / ty);
         const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
         const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
-        best = StreamTuning{ty, zc, 1};
+        best = StreamTuning{ty, zc, 1, tile_x};
         if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
     }
     return best;
 }
 
-template <int R, int TY, bool DAMP, bool FULL, int PF>
-static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a, int zchunk,
-                                     hipStream_t s) {
-    const int nxt = (int)(round_up(g.nx, TILE_X) / TILE_X);
+template <typename T, int R, int TY, bool DAMP, bool FULL, int PF>
+static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
+    constexpr int TX = 64 * VecOf<T>::VL;
+    const int nxt = stream_nxt(g, TX);
     const int nyt = (g.ny + TY - 1) / TY;
     const int nzc = (g.nz + zchunk - 1) / zchunk;
     const int nblk = nxt * nyt * nzc;
@@ -553,52 +593,58 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<float> &a
     static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
     if (no_remap) zchunk = -zchunk;
     if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in && a.q_in2)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else
-        hipLaunchKernelGGL((step3d_stream<R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     return hipGetLastError();
 }
 
-template <int R, int TY, bool DAMP>
-static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<float> &a, int zchunk, int pf,
-                                     hipStream_t s) {
+template <typename T, int R, int TY, bool DAMP>
+static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
     // FULL: every thread of every tile owns grid points, so the stores need no predicate.
-    // The prefetch depth is a tuning knob of the O(8) kernel only.
     // Prefetch depth: PF = 1 plane ahead measured best (256^3: 39.5 us/step vs 40.0 / 40.2 for
     // PF = 2 / 3; 512^3 equal), i.e. the kernel is throughput- not latency-bound; deeper rings
     // only cost registers.  The template parameter stays for re-tuning.
-    (void)pf;
-    if (g.nx % TILE_X == 0 && g.ny % TY == 0) return launch_stream_full<R, TY, DAMP, true, 1>(g, a, zchunk, s);
-    return launch_stream_full<R, TY, DAMP, false, 1>(g, a, zchunk, s);
+    if (g.nx % (64 * VecOf<T>::VL) == 0 && g.ny % TY == 0)
+        return launch_stream_full<T, R, TY, DAMP, true, 1>(g, a, zchunk, s);
+    return launch_stream_full<T, R, TY, DAMP, false, 1>(g, a, zchunk, s);
 }
 
-template <int R>
-static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<float> &a, const StreamTuning &t,
-                                  hipStream_t s) {
+template <typename T, int R>
+static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t, hipStream_t s) {
     const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
     if (a.damp) {
         switch (t.ty) {
-            case 4: return launch_stream_mode<R, 4, true>(g, a, zc, t.pf, s);
-            default: return launch_stream_mode<R, 8, true>(g, a, zc, t.pf, s);
+            case 4: return launch_stream_mode<T, R, 4, true>(g, a, zc, s);
+            default: return launch_stream_mode<T, R, 8, true>(g, a, zc, s);
         }
     }
     switch (t.ty) {
-        case 4: return launch_stream_mode<R, 4, false>(g, a, zc, t.pf, s);
-        default: return launch_stream_mode<R, 8, false>(g, a, zc, t.pf, s);
+        case 4: return launch_stream_mode<T, R, 4, false>(g, a, zc, s);
+        default: return launch_stream_mode<T, R, 8, false>(g, a, zc, s);
+    }
+}
+
+template <typename T>
+static hipError_t launch_stream(const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t, hipStream_t s) {
+    switch (g.r) {
+        case 1: return launch_stream_r<T, 1>(g, a, t, s);
+        case 2: return launch_stream_r<T, 2>(g, a, t, s);
+        default: return launch_stream_r<T, 4>(g, a, t, s);
     }
 }
 
 template <int R, int TY, bool DAMP>
 static hipError_t launch_tile2d_mode(const GridDesc &g, const StepArgs<float> &a, hipStream_t s) {
-    const int nxt = stream_nxt(g);
+    const int nxt = stream_nxt(g, TILE_X);
     const int nblk = nxt * ((g.nz + TY - 1) / TY);
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
     dim3 block(64, TY), grid(nblk + nrb);
@@ -689,19 +735,14 @@ hipError_t launch_step<float>(int kernel, const GridDesc &g, const StepArgs<floa
             default: return launch_tile2d_r<4>(g, a, t, s);
         }
     }
-    if (kernel == K_STREAM) {
-        switch (g.r) {
-            case 1: return launch_stream_r<1>(g, a, t, s);
-            case 2: return launch_stream_r<2>(g, a, t, s);
-            default: return launch_stream_r<4>(g, a, t, s);
-        }
-    }
+    if (kernel == K_STREAM) return launch_stream<float>(g, a, t, s);
     return launch_point<float>(g, a, s);
 }
 
 template <>
-hipError_t launch_step<double>(int, const GridDesc &g, const StepArgs<double> &a, const StreamTuning &,
+hipError_t launch_step<double>(int kernel, const GridDesc &g, const StepArgs<double> &a, const StreamTuning &t,
                                hipStream_t s) {
+    if (kernel == K_STREAM && g.ndim == 3) return launch_stream<double>(g, a, t, s);
     return launch_point<double>(g, a, s);
 }
 

@@ -94,15 +94,16 @@ def test_random_model_vs_oracle(gpu, shape, order, npml, dtype, tol):
 
 
 @pytest.mark.parametrize("zchunk", [0, 5, 16, 1000])
-def test_stream_kernel_matches_point_kernel(gpu, zchunk):
-    """Same inputs through both stencil kernels (and several z-chunkings)."""
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-6), ("float64", 1e-12)])
+def test_stream_kernel_matches_point_kernel(gpu, zchunk, dtype, tol):
+    """Same inputs through both stencil kernels (and several z-chunkings), fp32 and fp64."""
     w = workloads.cfg4(0.25, npml=6)  # 64^3
-    wav = w.wavelet()
-    a = run_gpu(w.c, w.h, w.dt, w.order, w.npml, None, w.src_idx, wav, w.rec_idx, kernel="point")
+    wav = w.wavelet(np.dtype(dtype).type)
+    a = run_gpu(w.c, w.h, w.dt, w.order, w.npml, None, w.src_idx, wav, w.rec_idx, kernel="point", dtype=dtype)
     b = run_gpu(w.c, w.h, w.dt, w.order, w.npml, None, w.src_idx, wav, w.rec_idx, kernel="stream",
-                zchunk=zchunk)
+                zchunk=zchunk, dtype=dtype)
     assert a["kernel"] == "step_point" and b["kernel"] == "step3d_stream"
-    assert rel(b["seis"], a["seis"]) < 2e-6
+    assert rel(b["seis"], a["seis"]) < tol
 
 
 # ---------------------------------------------------------------------------
@@ -214,9 +215,10 @@ def test_error_paths(gpu):
         assert ei.value.code == 3  # imaging needs save=True
         with pytest.raises(FwiError):
             e.set_model(np.zeros_like(c))  # velocity must be > 0
-    with pytest.raises(FwiError):
-        Engine((8, 8, 8), 10.0, 1e-3, 4, dtype="float64", kernel="stream").set_model(
-            np.full((8, 8, 8), 2000.0))
+    with pytest.raises(FwiError):  # the fp64 float4-style kernels exist in 3-D only
+        Engine((8, 8), 10.0, 1e-3, 4, dtype="float64", kernel="stream")
+    with pytest.raises(FwiError):  # odd nx cannot be covered by double2 lanes
+        Engine((8, 8, 9), 10.0, 1e-3, 4, dtype="float64", kernel="stream")
 
 
 def test_dot_product_reduction(gpu):

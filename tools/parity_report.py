@@ -64,7 +64,9 @@ def main():
         case("cfg4 96^3 x375", workloads.cfg4(0.375)),
         case("cfg4 128^3 x500", workloads.cfg4(0.5)),
         case("cfg4 128^3 x500 point", workloads.cfg4(0.5), kernel="point"),
-        case("cfg4 128^3 x500 fp64", workloads.cfg4(0.5), dtype="float64", kernel="point"),
+        case("cfg4 128^3 x500 fp64 point", workloads.cfg4(0.5), dtype="float64", kernel="point"),
+        case("cfg4 128^3 x500 fp64 stream", workloads.cfg4(0.5), dtype="float64"),
+        case("cfg5 128^3 x500 fp64 stream", workloads.cfg5(0.5), dtype="float64"),
         case("cfg5 64^3 x250", workloads.cfg5(0.25)),
         case("cfg5 128^3 x500", workloads.cfg5(0.5)),
     ]
