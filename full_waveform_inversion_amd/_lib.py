@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -51,6 +51,7 @@ SIGNATURES = {
     "fwi_adjoint": (C.c_int, [_P, _P, _I32, _P]),
     "fwi_gradient": (C.c_int, [_P, _I32, _P]),
     "fwi_gradient_reset": (C.c_int, [_P]),
+    "fwi_gradient_add": (C.c_int, [_P, _P]),
     "fwi_dot": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_D)]),
     "fwi_comm_unique_id": (C.c_int, [_P]),
     "fwi_comm_init": (C.c_int, [_P, _I32, _I32, _P]),

@@ -851,6 +851,21 @@ int fwi_gradient_reset(fwi_ctx *ctx) {
     return FWI_OK;
 }
 
+int fwi_gradient_add(fwi_ctx *dst, fwi_ctx *src) {
+    if (!dst || !src) return FWI_EINVAL;
+    if (dst == src) return dst->fail(FWI_EINVAL, "fwi_gradient_add: dst and src are the same context");
+    if (dst->cfg.device != src->cfg.device || dst->cfg.dtype != src->cfg.dtype || dst->gd.npts != src->gd.npts ||
+        dst->gd.nx != src->gd.nx || dst->gd.nz != src->gd.nz)
+        return dst->fail(FWI_EINVAL, "fwi_gradient_add: contexts differ in device, dtype or shape");
+    (void)hipSetDevice(dst->cfg.device);
+    HIPCHK(dst, hipStreamSynchronize(src->stream));  // src's adjoint sweeps are complete
+    int rc = DISPATCH(dst, Impl<float>::vec_axpby(dst, dst->g_acc, 1.0, src->g_acc, 1.0),
+                      Impl<double>::vec_axpby(dst, dst->g_acc, 1.0, src->g_acc, 1.0));
+    if (rc) return rc;
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    return FWI_OK;
+}
+
 int fwi_dot(fwi_ctx *ctx, const void *a, const void *b, int64_t n, double *out) {
     if (!ctx) return FWI_EINVAL;
     if (!a || !b || !out || n < 0) return ctx->fail(FWI_EINVAL, "fwi_dot: bad argument");

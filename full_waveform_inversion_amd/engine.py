@@ -166,6 +166,10 @@ class Engine:
         if self._ctx is not None:
             self._chk(self._lib.fwi_gradient_reset(self._ctx))
 
+    def gradient_add_from(self, other):
+        """This engine's gradient accumulator += ``other``'s (same shape, same GPU)."""
+        self._chk(self._lib.fwi_gradient_add(self._ctx, other._ctx))
+
     # -- reductions, exchange, measurement --------------------------------------
     def dot(self, a, b):
         a, b = self._host(a).ravel(), self._host(b).ravel()

@@ -80,13 +80,79 @@ class HostExchange:
         return g, float(tj[0])
 
 
+class EnginePool:
+    """Several engines (contexts + streams) on ONE GPU working through a rank's shots concurrently.
+
+    A 2-D shot is latency-bound and cannot fill an MI355X (1024^2: 7 us/step alone, 3.5 us/step/shot
+    with four in flight); independent shots overlap when each has its own context and is driven
+    by its own host thread (ctypes releases the GIL during the C-ABI calls).  3-D shots are
+    bandwidth-bound: use a pool of one.  Engines after the first only add into the first one's
+    gradient accumulator, which also owns the RCCL communicator.
+    """
+
+    def __init__(self, make_engine, size):
+        self.engines = [make_engine() for _ in range(max(1, int(size)))]
+
+    @property
+    def primary(self):
+        return self.engines[0]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def map_shots(self, indices, fn):
+        """Run ``fn(engine, shot_index)`` for every index, engines working in parallel; returns the
+        results in index order."""
+        import threading
+        indices = list(indices)
+        out = [None] * len(indices)
+        err = []
+
+        def work(k):
+            e = self.engines[k]
+            try:
+                for pos in range(k, len(indices), len(self.engines)):
+                    out[pos] = fn(e, indices[pos])
+            except BaseException as ex:  # re-raised in the caller's thread
+                err.append(ex)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(self.engines))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+
+def _engines(engine):
+    return engine.engines if isinstance(engine, EnginePool) else [engine]
+
+
 def model_data(engine, model, shots, exchange=None):
     """Synthesise observed data for the shots this rank owns (in place, returns the shots)."""
     ex = exchange or NoExchange()
-    engine.set_model(model)
-    for i in partition_shots(len(shots), ex.rank, ex.world):
+    for e in _engines(engine):
+        e.set_model(model)
+
+    def one(e, i):
         s = shots[i]
-        s.d_obs = engine.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=False)
+        s.d_obs = e.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=False)
+
+    mine = partition_shots(len(shots), ex.rank, ex.world)
+    if isinstance(engine, EnginePool):
+        engine.map_shots(mine, one)
+    else:
+        for i in mine:
+            one(engine, i)
     return shots
 
 
@@ -99,18 +165,32 @@ def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", obj
     from .objectives import l2
     objective = objective or l2
     ex = exchange or NoExchange()
-    engine.set_model(model)
-    engine.reset_gradient()
-    misfit = 0.0
-    for i in partition_shots(len(shots), ex.rank, ex.world):
+    for e in _engines(engine):
+        e.set_model(model)
+        e.reset_gradient()
+    misfit = _sweep_shots(engine, shots, ex, objective)
+    return ex.reduce(_engines(engine)[0], misfit, wrt)[::-1]
+
+
+def _sweep_shots(engine, shots, ex, objective):
+    """forward + adjoint of this rank's shots; returns the misfit, gradients summed into the
+    (primary) engine's accumulator."""
+    def one(e, i):
         s = shots[i]
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
-        d = engine.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
+        d = e.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
         j, r = objective(d, s.d_obs)
-        misfit += j
-        engine.adjoint(r)
-    return ex.reduce(engine, misfit, wrt)[::-1]
+        e.adjoint(r)
+        return j
+
+    mine = partition_shots(len(shots), ex.rank, ex.world)
+    if isinstance(engine, EnginePool):
+        misfit = float(sum(engine.map_shots(mine, one)))
+        for other in engine.engines[1:]:
+            engine.primary.gradient_add_from(other)
+        return misfit
+    return float(sum(one(engine, i) for i in mine))
 
 
 def misfit_and_gradient_device(engine, model_slot, grad_slot, shots, exchange=None, wrt="velocity",
@@ -120,17 +200,15 @@ def misfit_and_gradient_device(engine, model_slot, grad_slot, shots, exchange=No
     from .objectives import l2
     objective = objective or l2
     ex = exchange or NoExchange()
-    engine.set_model_vec(model_slot)
-    engine.reset_gradient()
-    misfit = 0.0
-    for i in partition_shots(len(shots), ex.rank, ex.world):
-        s = shots[i]
-        if s.d_obs is None:
-            raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
-        d = engine.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
-        j, r = objective(d, s.d_obs)
-        misfit += j
-        engine.adjoint(r)
-    misfit = ex.reduce_device(engine, misfit)
-    engine.gradient_vec(grad_slot, wrt)
+    engs = _engines(engine)
+    engs[0].set_model_vec(model_slot)
+    if len(engs) > 1:  # the optimiser's vectors live in the primary engine: hand the model over
+        model = engs[0].vec_download(model_slot)
+        for e in engs[1:]:
+            e.set_model(model)
+    for e in engs:
+        e.reset_gradient()
+    misfit = _sweep_shots(engine, shots, ex, objective)
+    misfit = ex.reduce_device(engs[0], misfit)
+    engs[0].gradient_vec(grad_slot, wrt)
     return misfit

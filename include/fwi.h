@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 4
+#define FWI_ABI_VERSION 5
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -116,6 +116,10 @@ int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src
  * [SURVEY s.8(a-1) row gradient] */
 int fwi_gradient(fwi_ctx *ctx, int32_t wrt, void *g_out);
 int fwi_gradient_reset(fwi_ctx *ctx);
+/* dst accumulator += src accumulator (two contexts of the same shape on the same GPU): several
+ * contexts can work through a rank's shots concurrently -- a 2-D shot cannot fill an MI355X on
+ * its own -- and are summed on the device before the exchange. */
+int fwi_gradient_add(fwi_ctx *dst, fwi_ctx *src);
 
 /* Device-side reductions for the misfit and the optimiser's dot products:
  * sum_i a[i]*b[i] over n host elements of the context dtype, wave-shuffle

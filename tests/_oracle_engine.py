@@ -37,5 +37,11 @@ class OracleEngine:
     def gradient(self, wrt="velocity"):
         return self._g if wrt == "slowness2" else self._g * (-2.0 / self._p.c ** 3)
 
+    def gradient_add_from(self, other):
+        self._g += other._g
+
+    def close(self):
+        pass
+
     def dot(self, a, b):
         return float(np.vdot(np.asarray(a, np.float64), np.asarray(b, np.float64)))

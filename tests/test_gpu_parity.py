@@ -394,3 +394,28 @@ def test_store_too_large_is_a_clean_error(gpu):
         assert ei.value.code == 4 and "ckpt_interval" in str(ei.value)
         d = e.forward(None, ([[8, 8, 8]], np.ones(4, np.float32)), [[9, 9, 9]], save=False)  # still usable
         assert d.shape == (4, 1)
+
+
+def test_engine_pool_on_gpu_matches_single_engine(gpu):
+    """2-D shots overlapped on one GPU (three contexts, three host threads) == one after the other."""
+    from full_waveform_inversion_amd import shots as sh
+
+    w = workloads.cfg3(0.125, nshots=6)
+    wav = w.wavelet()
+
+    def mk():
+        return Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=900.0)
+
+    a = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(6)]
+    b = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(6)]
+    c0 = (0.97 * w.c_init).astype(np.float32)
+    with mk() as e:
+        sh.model_data(e, w.c.astype(np.float32), a)
+        J1, g1 = sh.misfit_and_gradient(e, c0, a)
+    with sh.EnginePool(mk, 3) as pool:
+        sh.model_data(pool, w.c.astype(np.float32), b)
+        J3, g3 = sh.misfit_and_gradient(pool, c0, b)
+        with pytest.raises(FwiError):
+            pool.primary.gradient_add_from(pool.primary)
+    assert all(np.array_equal(x.d_obs, y.d_obs) for x, y in zip(a, b))
+    assert abs(J3 - J1) < 1e-6 * J1 and rel(g3, g1) < 1e-6

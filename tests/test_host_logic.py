@@ -113,3 +113,31 @@ def test_small_inversion_reduces_misfit_with_oracle_engine():
     _, _, log = lbfgs(lambda m: sh.misfit_and_gradient(e, m, shots), w.c_init, maxiter=4, history=4,
                       first_step=30.0, bounds=(1000.0, 4000.0))
     assert log[-1]["f"] < 0.5 * log[0]["f"]
+
+
+def test_engine_pool_matches_single_engine():
+    """Three engines sharing the shots (threads) give the single-engine misfit and gradient."""
+    w = workloads.cfg3(0.0625, nshots=5)
+    wav = w.wavelet(np.float64)
+
+    def mk():
+        return OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=800.0)
+
+    shots1 = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(5)]
+    shots3 = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(5)]
+    e = mk()
+    sh.model_data(e, w.c, shots1)
+    J1, g1 = sh.misfit_and_gradient(e, w.c_init, shots1)
+    with sh.EnginePool(mk, 3) as pool:
+        sh.model_data(pool, w.c, shots3)
+        assert all(np.array_equal(a.d_obs, b.d_obs) for a, b in zip(shots1, shots3))
+        J3, g3 = sh.misfit_and_gradient(pool, w.c_init, shots3)
+    assert abs(J3 - J1) <= 1e-13 * J1 and np.linalg.norm(g3 - g1) <= 1e-13 * np.linalg.norm(g1)
+
+
+def test_engine_pool_propagates_worker_errors():
+    w = workloads.cfg3(0.0625, nshots=3)
+    shots = [sh.Shot(w.src_idx[i:i + 1], w.wavelet(np.float64), w.rec_idx) for i in range(3)]  # no d_obs
+    with sh.EnginePool(lambda: OracleEngine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml), 2) as pool:
+        with pytest.raises(ValueError):
+            sh.misfit_and_gradient(pool, w.c_init, shots)

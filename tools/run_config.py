@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--shots", type=int, default=0, help="0 = the config's own count (32 / 64)")
     ap.add_argument("--iters", type=int, default=0, help="L-BFGS iterations; 0 = one gradient only")
     ap.add_argument("--host-lbfgs", action="store_true", help="keep the optimiser vectors on the host")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="engines sharing this GPU's shots concurrently; 0 = auto (4 in 2-D, 1 in 3-D)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -33,7 +35,12 @@ def main():
     w = workloads.CONFIGS[a.config](a.scale, **kw)
     wav = w.wavelet()
     shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(len(w.src_idx))]
-    e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local)
+    psize = a.pool or (4 if w.ndim == 2 else 1)
+    from full_waveform_inversion_amd import default_sigma_max
+    sigma = default_sigma_max(float(w.c.max()), w.h, w.npml)
+    pool = sh.EnginePool(lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
+                                        sigma_max=sigma), psize)
+    e = pool.primary
     ex = sh.NoExchange()
     dist = None
     if world > 1:
@@ -46,20 +53,20 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
         ex = sh.RcclExchange(e, rank, world, bcast)
-    sh.model_data(e, w.c.astype(np.float32), shots, ex)
+    sh.model_data(pool, w.c.astype(np.float32), shots, ex)
     t0 = time.perf_counter()
     evals = [0]
 
     def fg(m):
         evals[0] += 1
-        return sh.misfit_and_gradient(e, m, shots, ex)
+        return sh.misfit_and_gradient(pool, m, shots, ex)
 
     m0 = w.c_init.astype(np.float32)
     bounds = (0.5 * float(w.c.min()), 1.5 * float(w.c.max()))
     if a.iters > 0 and not a.host_lbfgs:
         def fg_dev(xs, gs):
             evals[0] += 1
-            return sh.misfit_and_gradient_device(e, xs, gs, shots, ex)
+            return sh.misfit_and_gradient_device(pool, xs, gs, shots, ex)
         _, _, log = lbfgs_device(e, fg_dev, m0, maxiter=a.iters, history=5, first_step=0.02 * float(m0.max()),
                                  bounds=bounds)
     elif a.iters > 0:
@@ -72,10 +79,10 @@ def main():
     if rank == 0:
         upd = 2 * evals[0] * len(shots) * w.updates_per_shot  # forward + adjoint sweeps
         print(json.dumps({"config": w.name, "shape": list(w.shape), "nt": w.nt, "shots": len(shots),
-                          "n_gpus": world, "evaluations": evals[0], "seconds": round(el, 3),
+                          "n_gpus": world, "engines_per_gpu": psize, "evaluations": evals[0], "seconds": round(el, 3),
                           "Gpts_per_s_fwd_plus_adj": round(upd / el / 1e9, 2), "kernel": e.kernel_name,
                           "log": log}))
-    e.close()
+    pool.close()
     if dist is not None:
         dist.destroy_process_group()
 
