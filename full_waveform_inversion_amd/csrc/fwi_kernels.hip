@@ -107,20 +107,24 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
 }
 
 // ---------------------------------------------------------------------------
-// STREAM kernel (3-D, fp32): a workgroup of 64 x TY threads owns a 256 x TY
-// (x, y) tile and marches `zchunk` planes in z.  Each thread owns one float4
-// (4 consecutive x) per plane: every global access is a coalesced 16 B/lane
-// stream, a wave covers 1 KiB of one row.
-//   z neighbours : 2r+1 deep register queue, fed one plane ahead of use.
+// STREAM kernel (3-D, fp32 and fp64): a workgroup of 64 x TY threads owns a
+// (64 VL) x TY (x, y) tile -- VL = 4 floats or 2 doubles per lane -- and marches
+// `zchunk` planes in z.  Each thread owns one 16-byte vector (VL consecutive x)
+// per plane: every global access is a coalesced 16 B/lane stream, a wave
+// covers 1 KiB of one row.
+//   z neighbours : register queue of 2r+2 vectors, the next plane fetched
+//                  straight into it one plane ahead; z loop unrolled by the
+//                  queue length so all indices are static (no rotation).
 //   y neighbours : the current plane's TY + 2r rows staged in LDS (double
 //                  buffered, so ONE barrier per plane); the 2r halo rows are
-//                  fetched one plane ahead by the waves themselves.
-//   x neighbours : the row's left/right float4 read back from the same LDS
-//                  row (lanes 0 / 63 add the 16 B edge pieces).
-// Algorithmic traffic 16 B/point (u_cur, u_prev, C in; u_next out); the halo
-// re-reads ((TY+2r)/TY in y, (zchunk+2r)/zchunk in z) are L2 / Infinity Cache
-// traffic.  Blocks are renumbered so each XCD (private 4 MiB L2) owns a
-// contiguous slab of tiles and shares those halo rows on chip.
+//                  fetched r planes ahead (right behind the neighbouring tile
+//                  streaming them) by the waves themselves.
+//   x neighbours : the row's left/right vectors read back from the same LDS
+//                  row (lanes 0-3 / 60-63 add the 4 edge elements per side).
+// Algorithmic traffic 16 B/point in fp32 (u_cur, u_prev, C in; u_next out);
+// the halo re-reads ((TY+2r)/TY in y, (zchunk+2r)/zchunk in z) are L2 /
+// Infinity Cache traffic.  Blocks are renumbered so each XCD (private 4 MiB
+// L2) owns a contiguous slab of tiles and shares those halo rows on chip.
 // ---------------------------------------------------------------------------
 // 16-byte vector of the field type: float4 / double2.  One per lane = 1 KiB per wave-instruction.
 template <typename T> struct VecOf;
