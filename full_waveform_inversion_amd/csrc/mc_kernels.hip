@@ -18,7 +18,7 @@
 
 namespace fwi {
 
-constexpr int SPB = 8;        // samples per workgroup (G is re-read once per workgroup)
+constexpr int SPB = 4;        // samples per workgroup (G is re-read once per workgroup)
 constexpr int MC_THREADS = 256;
 // moments per (sample, trace)
 enum { M_S1 = 0, M_S2, M_DS, M_MAX, M_SS1, M_DS1, M_D1S, M_FIRST, M_LAST, NMOM };
@@ -86,12 +86,36 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
         for (int s = 0; s < SPB; ++s) a1[s] = a2[s] = ads[s] = amx[s] = ass1[s] = ads1[s] = ad1s[s] = 0.0;
         const double *Gk = G + (int64_t)kk * n * t;
         const double *dk = d + (int64_t)kk * t;
+        // software pipeline (NC > 0, no lag terms): the G column and data sample of time index
+        // e + 64 are fetched (address clamped, branch-free) while index e is being accumulated
+        double gp[NC > 0 ? NC : 1], dp = 0.0;
+        if (NC > 0 && !LAG) {
+            const int e0 = min(lane, t - 1);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) gp[j] = Gk[(int64_t)j * t + e0];
+            dp = dk[e0];
+        }
         for (int e = lane; e < t; e += 64) {
             double sv[SPB], sn[SPB];
 #pragma unroll
             for (int s = 0; s < SPB; ++s) sv[s] = sn[s] = 0.0;
             const bool has_next = LAG && (e + 1 < t);
-            if (NC > 0) {
+            double dv_pf = 0.0;
+            if (NC > 0 && !LAG) {
+                double g[NC > 0 ? NC : 1];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) g[j] = gp[j];
+                dv_pf = dp;
+                const int en = min(e + 64, t - 1);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) gp[j] = Gk[(int64_t)j * t + en];
+                dp = dk[en];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {  // same j order as the reference's accumulation
+#pragma unroll
+                    for (int s = 0; s < SPB; ++s) sv[s] += g[j] * Mloc[j * SPB + s];
+                }
+            } else if (NC > 0) {
                 double g[NC > 0 ? NC : 1], gn[NC > 0 ? NC : 1];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
@@ -99,11 +123,11 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
                     gn[j] = has_next ? Gk[(int64_t)j * t + e + 1] : 0.0;
                 }
 #pragma unroll
-                for (int j = 0; j < NC; ++j) {  // same j order as the reference's accumulation
+                for (int j = 0; j < NC; ++j) {
 #pragma unroll
                     for (int s = 0; s < SPB; ++s) {
                         sv[s] += g[j] * Mloc[j * SPB + s];
-                        if (LAG) sn[s] += gn[j] * Mloc[j * SPB + s];
+                        sn[s] += gn[j] * Mloc[j * SPB + s];
                     }
                 }
             } else {
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
                     }
                 }
             }
-            const double dv = dk[e];
+            const double dv = (NC > 0 && !LAG) ? dv_pf : dk[e];
             const double dn = has_next ? dk[e + 1] : 0.0;
 #pragma unroll
             for (int s = 0; s < SPB; ++s) {
