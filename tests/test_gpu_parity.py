@@ -154,10 +154,24 @@ def test_full_size_3d_adjoint_identity_and_linearity(gpu):
         assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs))
 
 
+def test_full_size_3d_headline_config_vs_c_oracle(gpu):
+    """BASELINE configs[3] at FULL size (256^3, O(8), 1000 steps, what bench.py times): the OpenMP C
+    oracle needs ~10 s for it, so the headline run itself is checked, not a scaled copy."""
+    w = workloads.cfg4(1.0)
+    wav = w.wavelet(np.float64)
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    d = p.forward(w.src_idx, wav, w.rec_idx, save=False)
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) as e:
+        dg = e.forward(w.c, (w.src_idx, wav), w.rec_idx, save=False)
+        assert e.kernel_name == "step3d_stream"
+    assert np.abs(d).max() > 0
+    assert rel(dg, d) < TOL32
+
+
 def test_full_size_2d_vs_c_oracle(gpu):
-    """cfg2 at full 1024^2 grid, 400 steps: the C oracle still finishes in seconds."""
+    """cfg2 at FULL size (1024^2, O(8) + sponge, 2000 steps): the C oracle finishes in seconds."""
     w = workloads.cfg2(1.0)
-    nt = 400
+    nt = w.nt
     wav = w.wavelet(np.float64)[:nt]
     p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
     d = p.forward(w.src_idx, wav, w.rec_idx, save=False)
