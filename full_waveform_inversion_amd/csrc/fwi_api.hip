@@ -758,11 +758,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         }
         if (const char *ty = getenv("FWI_STREAM_TY")) {  // tuning hook: rows per workgroup
             const int v = atoi(ty);
-            if (v == 4 || v == 8 || v == 16) {
-                ctx->tune.ty = v;
-                // 3-D: 16-row tiles are made of half-width rows (two per wave)
-                if (cfg->ndim == 3) ctx->tune.tile_x = (cfg->dtype == FWI_F32 ? 256 : 128) / (v == 16 ? 2 : 1);
-            }
+            if (v == 4 || v == 8 || (v == 16 && cfg->ndim == 2)) ctx->tune.ty = v;
         }
     }
     int rc = create_impl(ctx);

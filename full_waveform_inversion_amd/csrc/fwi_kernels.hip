@@ -185,31 +185,25 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 
 // IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
-// LPR = lanes per tile row: 64 (a wave = one row of 64 vectors) or 32 (a wave = two rows of 32, i.e.
-// tiles half as wide and twice as tall: the y-halo re-read drops from (TY+2r)/TY to (2TY+2r)/2TY).
-template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, int LPR>
+template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk) {
-    constexpr int RPW = 64 / LPR;                // tile rows per wave
-    constexpr int TYE = TY * RPW;                // tile rows per workgroup
-    constexpr int NH = (2 * R + TYE - 1) / TYE;  // halo rows each thread fetches per plane
-    constexpr int TRASH = TYE + 2 * R;           // LDS row that absorbs the writes of idle slots
-    constexpr int LROWS = TYE + 2 * R + 1;
+    constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
+    constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
+    constexpr int LROWS = TY + 2 * R + 1;
     constexpr int VL = VecOf<T>::VL;       // elements per lane: float4 / double2
     constexpr int HV = HALO / VL;          // vectors per x-halo side (1 / 2)
-    constexpr int TX = LPR * VL;           // tile row in elements
-    constexpr int LROWV = LPR + 2 * HV;    // LDS row in vectors: [left edge][LPR lanes][right edge]
+    constexpr int TX = 64 * VL;            // tile row in elements (256 / 128)
+    constexpr int LROWV = 64 + 2 * HV;     // LDS row in vectors: [left edge][64 lanes][right edge]
     using V = vec<T>;
     __shared__ V lds[2][LROWS][LROWV];
 
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int lane = threadIdx.x % LPR;                     // vector within the tile row
-    const int ty = threadIdx.y * RPW + threadIdx.x / LPR;   // row within the tile
+    const int lane = threadIdx.x, ty = threadIdx.y;
     int bid = blockIdx.x;
     if (bid >= nblk) {
         // Receiver sampling rides along as extra workgroups: u_cur is read-only in this
         // launch and already holds the previous step's field including its injection.
-        for (int i = (bid - nblk) * (64 * TY) + tid; i < a.nrec; i += (gridDim.x - nblk) * 64 * TY)
+        for (int i = (bid - nblk) * (64 * TY) + ty * 64 + lane; i < a.nrec; i += (gridDim.x - nblk) * 64 * TY)
             a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
         return;
     }
@@ -219,7 +213,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     const int t2 = bid / nxt;
     const int by = t2 % nyt, bz = t2 / nyt;
     const int x0 = bx * TX + VL * lane;
-    const int y0 = by * TYE, y = y0 + ty;
+    const int y0 = by * TY, y = y0 + ty;
     const int z0 = bz * zchunk;
     const int z1 = min(g.nz, z0 + zchunk);
     const bool act = FULL || ((x0 < g.nx) && (y < g.ny));
@@ -242,19 +236,18 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     int hrow[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-        const int hr = ty + i * TYE;
+        const int hr = ty + i * TY;
         const bool valid = hr < 2 * R;
-        const int yh = !valid ? y : (hr < R) ? y0 - R + hr : y0 + TYE + (hr - R);
-        hrow[i] = !valid ? TRASH : (hr < R) ? hr : TYE + hr;
+        const int yh = !valid ? y : (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
+        hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
         hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + x0);
     }
-    // x edges: lanes 0-3 of a row fetch the 4 elements left of the tile row, its last 4 lanes
+    // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
     // the 4 elements right of it (one scalar load each).
     const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TX);
-    constexpr int EL = LPR - 4;  // first of the 4 lanes that fetch the right edge
-    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= EL) ? rowoff + TX + (lane - EL) : poff;
-    const int erow = (lane < 4 || lane >= EL) ? R + ty : TRASH;
-    const int ecol = (lane < 4) ? lane : (lane >= EL) ? (HV + LPR) * VL + (lane - EL) : (HV + lane) * VL;
+    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : poff;
+    const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : (HV + lane) * VL;
 
     // loop-invariant xy part of the damping
     V Axy, Bxy, dxy;
@@ -417,7 +410,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
         if (s1 > s0) {
             __syncthreads();
-            for (int i = s0 + tid; i < s1; i += 64 * TY) {
+            for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
                 const T amp = a.inj_amp[a.inj_col[i]];
                 atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
                 if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
@@ -594,12 +587,11 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
     return best;
 }
 
-template <typename T, int R, int TY, bool DAMP, bool FULL, int PF, int LPR>
+template <typename T, int R, int TY, bool DAMP, bool FULL, int PF>
 static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
-    constexpr int TX = LPR * VecOf<T>::VL;
-    constexpr int TYE = TY * (64 / LPR);
+    constexpr int TX = 64 * VecOf<T>::VL;
     const int nxt = stream_nxt(g, TX);
-    const int nyt = (g.ny + TYE - 1) / TYE;
+    const int nyt = (g.ny + TY - 1) / TY;
     const int nzc = (g.nz + zchunk - 1) / zchunk;
     const int nblk = nxt * nyt * nzc;
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
@@ -607,46 +599,43 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
     static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
     if (no_remap) zchunk = -zchunk;
     if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, LPR>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in && a.q_in2)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, LPR>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, LPR>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     else
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, LPR>), grid, block, 0, s, a, g,
+        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk);
     return hipGetLastError();
 }
 
-template <typename T, int R, int TY, bool DAMP, int LPR>
+template <typename T, int R, int TY, bool DAMP>
 static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
     // FULL: every thread of every tile owns grid points, so the stores need no predicate.
     // Prefetch depth: PF = 1 plane ahead measured best (256^3: 39.5 us/step vs 40.0 / 40.2 for
     // PF = 2 / 3; 512^3 equal), i.e. the kernel is throughput- not latency-bound; deeper rings
     // only cost registers.  The template parameter stays for re-tuning.
-    if (g.nx % (LPR * VecOf<T>::VL) == 0 && g.ny % (TY * (64 / LPR)) == 0)
-        return launch_stream_full<T, R, TY, DAMP, true, 1, LPR>(g, a, zchunk, s);
-    return launch_stream_full<T, R, TY, DAMP, false, 1, LPR>(g, a, zchunk, s);
+    if (g.nx % (64 * VecOf<T>::VL) == 0 && g.ny % TY == 0)
+        return launch_stream_full<T, R, TY, DAMP, true, 1>(g, a, zchunk, s);
+    return launch_stream_full<T, R, TY, DAMP, false, 1>(g, a, zchunk, s);
 }
 
 template <typename T, int R>
 static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t, hipStream_t s) {
     const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
-    // t.ty = tile rows: 4 / 8 (one row per wave) or 16 (8 waves of two half-width rows)
     if (a.damp) {
         switch (t.ty) {
-            case 4: return launch_stream_mode<T, R, 4, true, 64>(g, a, zc, s);
-            case 16: return launch_stream_mode<T, R, 8, true, 32>(g, a, zc, s);
-            default: return launch_stream_mode<T, R, 8, true, 64>(g, a, zc, s);
+            case 4: return launch_stream_mode<T, R, 4, true>(g, a, zc, s);
+            default: return launch_stream_mode<T, R, 8, true>(g, a, zc, s);
         }
     }
     switch (t.ty) {
-        case 4: return launch_stream_mode<T, R, 4, false, 64>(g, a, zc, s);
-        case 16: return launch_stream_mode<T, R, 8, false, 32>(g, a, zc, s);
-        default: return launch_stream_mode<T, R, 8, false, 64>(g, a, zc, s);
+        case 4: return launch_stream_mode<T, R, 4, false>(g, a, zc, s);
+        default: return launch_stream_mode<T, R, 8, false>(g, a, zc, s);
     }
 }
 
