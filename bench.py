@@ -76,13 +76,16 @@ def main():
     ap.add_argument("--zchunk", type=int, default=0)
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
                     help="forward: the headline stencil run; gradient: forward(save) + adjoint(imaging) per step")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses device 0 (RCCL refuses duplicate GPUs, "
+                         "so this exercises the flagged fallback exchange)")
     ap.add_argument("--cpu-steps", type=int, default=1000,
                     help="time steps of the CPU baseline sample (1000 = the whole shot, ~12 s on 16 cores); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0 and world > 1:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
