@@ -433,3 +433,23 @@ def test_engine_pool_on_gpu_matches_single_engine(gpu):
             pool.primary.gradient_add_from(pool.primary)
     assert all(np.array_equal(x.d_obs, y.d_obs) for x, y in zip(a, b))
     assert abs(J3 - J1) < 1e-6 * J1 and rel(g3, g1) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 44), (60, 52)])
+def test_gpu_fp64_adjoint_identity(gpu, shape):
+    """<F s, r> = <s, F^T r> on the GPU itself in fp64 (1e-12): forward and adjoint kernels,
+    injection, sampling and their scalings are exact transposes -- no oracle involved."""
+    rng = np.random.default_rng(4)
+    nd = len(shape)
+    c = 1600.0 + 1400.0 * rng.random(shape)
+    dt = 0.7 * fo.cfl_dt(c.max(), 9.0, nd, 8)
+    nt = 80
+    src = np.stack([rng.integers(0, s, 3) for s in shape], 1)
+    rec = np.stack([rng.integers(0, s, 13) for s in shape], 1)
+    w = rng.standard_normal((nt, 3))
+    r = rng.standard_normal((nt, 13))
+    with Engine(shape, 9.0, dt, nt, order=8, npml=6, sigma_max=600.0, dtype="float64") as e:
+        d = e.forward(c, (src, w), rec, save=False)
+        a = e.adjoint(r, image=False)
+    lhs, rhs = float(np.sum(d * r)), float(np.sum(w * a))
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs))

@@ -186,3 +186,35 @@ def test_golden_fixtures(name):
     a = p.adjoint(z["residual"])
     assert rel(a, z["adj_src"]) < 1e-12
     assert rel(p.gradient(), z["grad_c"]) < 1e-11
+
+
+def test_observed_convergence_orders():
+    """SURVEY s.4 tier 1: error vs the analytic 3-D solution falls with order ~8 in space when dt is
+    small enough, and with order ~2 in time at fixed fine space."""
+    c0, f0 = 2000.0, 8.0
+    L = 720.0            # physical box edge (m); source in the middle, receiver 180 m away
+    T = 0.30
+
+    def err(n, dt_frac, order=8):
+        h = L / n
+        dt = dt_frac * fo.cfl_dt(c0, h, 3, order)
+        nt = int(round(T / dt))
+        dt = T / nt
+        w = fo.ricker(nt, dt, f0)
+        mid = n // 2
+        off = int(round(180.0 / h))
+        p = fo.Propagator(np.full((n, n, n), c0), h, dt, order, npml=0)
+        d = p.forward([[mid, mid, mid]], w, [[mid, mid, mid + off]], save=False)[:, 0]
+        t = (np.arange(nt) + 1) * dt
+        r = off * h
+        # fine quadrature-free reference: the wavelet is analytic
+        a = (np.pi * f0 * (t - r / c0 - 1.5 / f0)) ** 2
+        ex = (1.0 - 2.0 * a) * np.exp(-a) / (4 * np.pi * r) * (t >= r / c0)
+        return np.linalg.norm(d - ex) / np.linalg.norm(ex)
+
+    # space: halve h at a tiny time step (time error negligible): order 8 => ratio >> 2^4
+    e_coarse, e_fine = err(24, 0.05), err(48, 0.05)
+    assert e_fine < e_coarse / 2 ** 4, (e_coarse, e_fine)
+    # time: fine space, halve dt: order 2 => ratio ~ 4
+    e1, e2 = err(48, 0.8), err(48, 0.4)
+    assert 2.5 < e1 / e2 < 6.0, (e1, e2)
