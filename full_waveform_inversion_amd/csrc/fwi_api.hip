@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/fwi.h"
@@ -73,6 +74,12 @@ struct fwi_ctx {
         void *s_start = nullptr, *s_pidx = nullptr, *s_cidx = nullptr, *s_cu = nullptr, *s_cq = nullptr,
              *s_col = nullptr;
         size_t cap = 0, cap_start = 0;
+        // tables for the 2-D fused kernel: injection entries per tile (extended region) and
+        // sampling entries per tile (interior)
+        void *fi_start = nullptr, *fi_lz = nullptr, *fi_lx = nullptr, *fi_col = nullptr, *fi_int = nullptr,
+             *fi_cidx = nullptr, *fi_cu = nullptr, *fi_cq = nullptr;
+        void *fr_start = nullptr, *fr_lz = nullptr, *fr_lx = nullptr, *fr_col = nullptr;
+        size_t fcap = 0, fcap_start = 0;
     } src, rec;
     void *wav = nullptr;     // (nt, nsrc) source wavelets of the last forward (kept for recomputation)
     void *amp = nullptr;     // (nt, nrec) residual being back-propagated
@@ -85,6 +92,10 @@ struct fwi_ctx {
     // imaging term of every step; q_store then holds ckpt + 1 slots and fwd[] the recomputed fields
     int ckpt = 0;
     void *snap = nullptr, *fwd[2] = {nullptr, nullptr};
+    // 2-D temporal blocking: second buffer pair the fused kernel writes into, and whether it is used
+    bool fused2d = false;
+    void *fx[2] = {nullptr, nullptr};   // second pair for the time sweep in flight
+    void *fwx[2] = {nullptr, nullptr};  // second pair for the checkpointed forward recomputation
 
     ncclComm_t comm = nullptr;
     int nranks = 1;
@@ -195,6 +206,14 @@ int flatten(fwi_ctx *ctx, const int32_t *idx, int n, std::vector<int64_t> &pidx,
 
 template <typename T>
 struct Impl {
+    // State of one field pair being stepped: which buffer holds the newest field, and the step
+    // whose sampling is still owed (it rides on the next launch).
+    struct Sweep {
+        void *f[2];
+        int cur = 0;
+        int prev_n = -1;
+    };
+
     static StepArgs<T> base_args(fwi_ctx *ctx, int cur) {
         StepArgs<T> a;
         a.u_cur = (const T *)ctx->u[cur];
@@ -343,9 +362,159 @@ struct Impl {
             HIPCHK(ctx, up(ps.s_cq, scq.data(), (size_t)n * sizeof(T)));
             HIPCHK(ctx, up(ps.s_col, col.data(), (size_t)n * sizeof(int)));
         }
+        std::vector<int> fst, flz, flx, fcol, rst, rlz, rlx, rcol;
+        std::vector<unsigned char> fint;
+        std::vector<int64_t> fcidx;
+        std::vector<T> fcu, fcq;
+        if (ctx->fused2d) {
+            // entries of the fused 2-D kernel: a point is injected by every tile whose EXTENDED region
+            // holds it (each keeps a private copy of the halo) and sampled by the one tile owning it
+            constexpr int FT = FUSED2D_TILE;
+            const int HL = FUSED2D_STEPS * g.r;
+            const int ntx = (g.nx + FT - 1) / FT, ntz = (g.nz + FT - 1) / FT, ntile = ntx * ntz;
+            struct Ent { int tile, lz, lx, col; unsigned char interior; };
+            std::vector<Ent> ents;
+            for (int i = 0; i < n; ++i) {
+                const int z = idx[(size_t)i * g.ndim], x = idx[(size_t)i * g.ndim + 1];
+                // HL < FT: only the owning tile and its direct neighbours can hold the point
+                for (int tz = std::max(0, z / FT - 1); tz <= std::min(ntz - 1, z / FT + 1); ++tz) {
+                    if (z < tz * FT - HL || z >= tz * FT + FT + HL) continue;
+                    for (int tx = std::max(0, x / FT - 1); tx <= std::min(ntx - 1, x / FT + 1); ++tx) {
+                        if (x < tx * FT - HL || x >= tx * FT + FT + HL) continue;
+                        const bool in = z / FT == tz && x / FT == tx;
+                        ents.push_back({tz * ntx + tx, z - (tz * FT - HL), x - (tx * FT - HL), i, (unsigned char)in});
+                    }
+                }
+            }
+            auto build = [&](bool interior_only, std::vector<int> &st, std::vector<int> &lz, std::vector<int> &lx,
+                             std::vector<int> &col, std::vector<int> *order) {
+                st.assign(ntile + 1, 0);
+                for (const Ent &e : ents)
+                    if (!interior_only || e.interior) ++st[e.tile + 1];
+                for (int k = 0; k < ntile; ++k) st[k + 1] += st[k];
+                std::vector<int> fill(st.begin(), st.end() - 1);
+                const int tot = st[ntile];
+                lz.resize(tot); lx.resize(tot); col.resize(tot);
+                if (order) order->resize(tot);
+                for (size_t q = 0; q < ents.size(); ++q) {
+                    const Ent &e = ents[q];
+                    if (interior_only && !e.interior) continue;
+                    const int k = fill[e.tile]++;
+                    lz[k] = e.lz; lx[k] = e.lx; col[k] = e.col;
+                    if (order) (*order)[k] = (int)q;
+                }
+            };
+            std::vector<int> order;
+            build(false, fst, flz, flx, fcol, &order);
+            build(true, rst, rlz, rlx, rcol, nullptr);
+            const size_t ne = order.size();
+            fint.resize(ne); fcidx.resize(ne); fcu.resize(ne); fcq.resize(ne);
+            for (size_t k = 0; k < ne; ++k) {
+                const Ent &e = ents[order[k]];
+                fint[k] = e.interior; fcidx[k] = c[e.col]; fcu[k] = cu[e.col]; fcq[k] = cq[e.col];
+            }
+            const size_t fneed = ne * 8 + 16, sneed = (size_t)(ntile + 1) * sizeof(int);
+            if (ps.fcap < fneed) {
+                for (void **q : {&ps.fi_lz, &ps.fi_lx, &ps.fi_col, &ps.fi_int, &ps.fi_cidx, &ps.fi_cu, &ps.fi_cq,
+                                 &ps.fr_lz, &ps.fr_lx, &ps.fr_col}) {
+                    if (*q) HIPCHK(ctx, hipFree(*q));
+                    *q = nullptr;
+                    HIPCHK(ctx, hipMalloc(q, fneed));
+                }
+                ps.fcap = fneed;
+            }
+            if (ps.fcap_start < sneed) {
+                for (void **q : {&ps.fi_start, &ps.fr_start}) {
+                    if (*q) HIPCHK(ctx, hipFree(*q));
+                    *q = nullptr;
+                    HIPCHK(ctx, hipMalloc(q, sneed));
+                }
+                ps.fcap_start = sneed;
+            }
+            HIPCHK(ctx, up(ps.fi_start, fst.data(), sneed));
+            HIPCHK(ctx, up(ps.fr_start, rst.data(), sneed));
+            HIPCHK(ctx, up(ps.fi_lz, flz.data(), ne * sizeof(int)));
+            HIPCHK(ctx, up(ps.fi_lx, flx.data(), ne * sizeof(int)));
+            HIPCHK(ctx, up(ps.fi_col, fcol.data(), ne * sizeof(int)));
+            HIPCHK(ctx, up(ps.fi_int, fint.data(), ne));
+            HIPCHK(ctx, up(ps.fi_cidx, fcidx.data(), ne * 8));
+            HIPCHK(ctx, up(ps.fi_cu, fcu.data(), ne * sizeof(T)));
+            HIPCHK(ctx, up(ps.fi_cq, fcq.data(), ne * sizeof(T)));
+            HIPCHK(ctx, up(ps.fr_lz, rlz.data(), rlz.size() * sizeof(int)));
+            HIPCHK(ctx, up(ps.fr_lx, rlx.data(), rlx.size() * sizeof(int)));
+            HIPCHK(ctx, up(ps.fr_col, rcol.data(), rcol.size() * sizeof(int)));
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
         ps.n = n;
         return FWI_OK;
+    }
+
+    // 2-D temporal blocking: `count` steps (a multiple of FUSED2D_STEPS) starting at n0 in direction
+    // dn, FUSED2D_STEPS per launch, ping-ponging between the buffer pair in `sw` and ctx->fx.
+    // Sampling is not lagged here (it happens inside the sub-steps): sw.prev_n stays -1.
+    static int run_fused(fwi_ctx *ctx, Sweep &sw, void **spare, int n0, int dn, int count,
+                         const fwi_ctx::PointSet &inj, const T *amp, const fwi_ctx::PointSet *out, T *series,
+                         T out_scale, int mode, T *q_base) {
+        if constexpr (std::is_same<T, float>::value) {
+            const GridDesc &g = ctx->gd;
+            const StepArgs<T> b = base_args(ctx, 0);
+            for (int done = 0; done < count; done += FUSED2D_STEPS) {
+                Fused2dArgs a{};
+                a.u_cur = (const float *)sw.f[sw.cur];
+                a.u_prev = (const float *)sw.f[sw.cur ^ 1];
+                a.C = (const float *)ctx->C;
+                a.out_cur = (float *)spare[0];
+                a.out_prev = (float *)spare[1];
+                a.dz = (const float *)ctx->dz;
+                a.dx = (const float *)ctx->dx;
+                for (int k = 0; k < 5; ++k) a.ck[k] = b.ck[k];
+                a.damp = b.damp;
+                a.mode = mode;
+                a.q_base = (float *)q_base;
+                a.g = (float *)ctx->g_acc;
+                a.n0 = n0 + done * dn;
+                a.dn = dn;
+                if (inj.n > 0) {
+                    a.inj_start = (const int *)inj.fi_start;
+                    a.inj_lz = (const int *)inj.fi_lz;
+                    a.inj_lx = (const int *)inj.fi_lx;
+                    a.inj_col = (const int *)inj.fi_col;
+                    a.inj_interior = (const unsigned char *)inj.fi_int;
+                    a.inj_cidx = (const int64_t *)inj.fi_cidx;
+                    a.inj_cu = (const float *)inj.fi_cu;
+                    a.inj_cq = (const float *)inj.fi_cq;
+                    a.inj_amp = (const float *)amp;
+                    a.ninj = inj.n;
+                }
+                if (out && out->n > 0) {
+                    a.rec_start = (const int *)out->fr_start;
+                    a.rec_lz = (const int *)out->fr_lz;
+                    a.rec_lx = (const int *)out->fr_lx;
+                    a.rec_col = (const int *)out->fr_col;
+                    a.rec_out = (float *)series;
+                    a.rec_scale = out_scale;
+                    a.nrec = out->n;
+                }
+                HIPCHK(ctx, launch_fused2d(g, a, ctx->stream));
+                // the freshly written pair becomes current; the old pair is the next launch's output
+                void *oc = sw.f[sw.cur], *op = sw.f[sw.cur ^ 1];
+                sw.f[0] = spare[0];
+                sw.f[1] = spare[1];
+                sw.cur = 0;
+                spare[0] = oc;
+                spare[1] = op;
+            }
+            sw.prev_n = -1;
+            return FWI_OK;
+        } else {
+            (void)sw; (void)spare; (void)n0; (void)dn; (void)count; (void)inj; (void)amp; (void)out; (void)series;
+            (void)out_scale; (void)mode; (void)q_base;
+            return ctx->fail(FWI_ESTATE, "fused 2-D path is fp32 only");
+        }
+    }
+
+    static bool use_fused(const fwi_ctx *ctx, int nt) {
+        return ctx->fused2d && nt % FUSED2D_STEPS == 0 && (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
     }
 
     static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
@@ -354,14 +523,6 @@ struct Impl {
         if (rc) return rc;
         return upload_set(ctx, ctx->rec, nrec, rec_idx, 1.0);
     }
-
-    // State of one field pair being stepped: which buffer holds the newest field, and the step
-    // whose sampling is still owed (it rides on the next launch).
-    struct Sweep {
-        void *f[2];
-        int cur = 0;
-        int prev_n = -1;
-    };
 
     // Steps n = n0, n0 + dn, ... (count steps) of the shared time loop (oracle:
     // Propagator._propagate): inject `amp` rows at point set `inj`, sample the new field at point
@@ -439,6 +600,12 @@ struct Impl {
             HIPCHK(ctx, hipMalloc(&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T)));  // K slots + carry
             HIPCHK(ctx, hipMalloc(&ctx->fwd[0], (size_t)g.ptot * sizeof(T)));
             HIPCHK(ctx, hipMalloc(&ctx->fwd[1], (size_t)g.ptot * sizeof(T)));
+            if (ctx->fused2d) {
+                HIPCHK(ctx, hipMalloc(&ctx->fwx[0], (size_t)g.ptot * sizeof(T)));
+                HIPCHK(ctx, hipMalloc(&ctx->fwx[1], (size_t)g.ptot * sizeof(T)));
+                HIPCHK(ctx, hipMemsetAsync(ctx->fwx[0], 0, (size_t)g.ptot * sizeof(T), ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->fwx[1], 0, (size_t)g.ptot * sizeof(T), ctx->stream));
+            }
         }
         if ((rc = ensure(ctx, &ctx->wav, &ctx->cap_wav, (size_t)nt * std::max(nsrc, 1) * sizeof(T)))) return rc;
         if ((rc = ensure(ctx, &ctx->amp, &ctx->cap_amp, (size_t)nt * std::max(nrec, 1) * sizeof(T)))) return rc;
@@ -460,6 +627,9 @@ struct Impl {
         T *series = (T *)ctx->series;
         auto none = [](int) -> T * { return nullptr; };
         auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
+        const bool fused = use_fused(ctx, nt);  // 2-D: FUSED2D_STEPS time steps per launch
+        void *spare[2] = {ctx->fx[0], ctx->fx[1]};
+        if (fused && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         if (save && K > 0) {
             for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
@@ -467,10 +637,19 @@ struct Impl {
                 HIPCHK(ctx, hipMemcpyAsync(sn, sw.f[sw.cur], (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
                 HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));
-                if ((rc = run_steps(ctx, sw, n0, 1, std::min(K, nt - n0), ctx->src, (const T *)ctx->wav, &ctx->rec,
-                                    series, T(1), none, noq)))
-                    return rc;
+                const int cnt = std::min(K, nt - n0);
+                if (fused)
+                    rc = run_fused(ctx, sw, spare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, &ctx->rec, series,
+                                   T(1), 0, nullptr);
+                else
+                    rc = run_steps(ctx, sw, n0, 1, cnt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1),
+                                   none, noq);
+                if (rc) return rc;
             }
+        } else if (fused) {
+            if ((rc = run_fused(ctx, sw, spare, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1),
+                                save ? 1 : 0, q_store)))
+                return rc;
         } else {
             auto qo = [&](int n) -> T * { return save ? q_store + (size_t)n * g.npts : nullptr; };
             if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, noq)))
@@ -479,6 +658,12 @@ struct Impl {
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
+        if (fused) {  // the buffer pairs may have changed roles: keep ownership consistent
+            ctx->u[0] = sw.f[0];
+            ctx->u[1] = sw.f[1];
+            ctx->fx[0] = spare[0];
+            ctx->fx[1] = spare[1];
+        }
         if ((rc = download_series(ctx, seis_out, ctx->series,
                                   (nrec && seis_out) ? (size_t)nt * nrec * sizeof(T) : 0)))
             return rc;
@@ -529,7 +714,45 @@ struct Impl {
                 }
             }
         };
-        if (image && K > 0) {
+        const bool fused = use_fused(ctx, nt);
+        void *spare[2] = {ctx->fx[0], ctx->fx[1]};
+        if (fused && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
+        bool imaged_all = false;  // the fused kernel pairs mu^{n+1} with q^n inside the launch (no lag)
+        if (fused && image && K > 0) {
+            // checkpointed, fused: recompute each segment's forward storing q into the slot buffer,
+            // then sweep the segment backwards imaging against those slots (no carry: nothing lags).
+            // The recomputation ping-pongs between its own two buffer pairs (fwd, fwx).
+            Sweep fw;
+            fw.f[0] = ctx->fwd[0];
+            fw.f[1] = ctx->fwd[1];
+            void *fspare[2] = {ctx->fwx[0], ctx->fwx[1]};
+            const int nseg = (nt + K - 1) / K;
+            for (int seg = nseg - 1; seg >= 0; --seg) {
+                const int n0 = seg * K, cnt = std::min(K, nt - n0);
+                const T *sn = (const T *)ctx->snap + (size_t)seg * 2 * g.ptot;
+                fw.cur = 0;
+                HIPCHK(ctx, hipMemcpyAsync(fw.f[0], sn, (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
+                HIPCHK(ctx, hipMemcpyAsync(fw.f[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
+                                           hipMemcpyDeviceToDevice, s));
+                T *qb = q_store - (size_t)n0 * g.npts;  // slot (n - n0) == qb + n * npts
+                if ((rc = run_fused(ctx, fw, fspare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr,
+                                    T(0), 1, qb)))
+                    return rc;
+                if ((rc = run_fused(ctx, sw, spare, n0 + cnt - 1, -1, cnt, ctx->rec, amp, &ctx->src, series, rs, 2,
+                                    qb)))
+                    return rc;
+            }
+            ctx->fwd[0] = fw.f[0];
+            ctx->fwd[1] = fw.f[1];
+            ctx->fwx[0] = fspare[0];
+            ctx->fwx[1] = fspare[1];
+            imaged_all = true;
+        } else if (fused) {
+            if ((rc = run_fused(ctx, sw, spare, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, image ? 2 : 0,
+                                q_store)))
+                return rc;
+            imaged_all = true;
+        } else if (image && K > 0) {
             // Checkpointed: per segment (last to first) restore the snapshot, recompute the forward
             // steps storing q into the K-slot buffer, then take the adjoint steps of that segment.
             // At a segment's first adjoint step q^{n+1} is the first q of the segment processed
@@ -568,8 +791,14 @@ struct Impl {
             if ((rc = run_steps(ctx, sw, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, none, qi))) return rc;
             q0 = q_store;
         }
+        if (fused) {  // the buffer pairs may have changed roles: keep ownership consistent
+            ctx->u[0] = sw.f[0];
+            ctx->u[1] = sw.f[1];
+            ctx->fx[0] = spare[0];
+            ctx->fx[1] = spare[1];
+        }
         if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
-        if (image)  // the last pairing: mu^1 with q^0
+        if (image && !imaged_all)  // the last pairing: mu^1 with q^0
             HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
@@ -702,7 +931,8 @@ const char *fwi_last_error(const fwi_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 const char *fwi_kernel_name(const fwi_ctx *ctx) {
     if (!ctx) return "";
-    if (ctx->kernel == K_STREAM) return ctx->gd.ndim == 3 ? "step3d_stream" : "step2d_tile";
+    if (ctx->kernel == K_STREAM && ctx->gd.ndim == 2) return ctx->fused2d ? "step2d_fused" : "step2d_tile";
+    if (ctx->kernel == K_STREAM) return "step3d_stream";
     return "step_point";
 }
 
@@ -761,7 +991,17 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
             if (v == 4 || v == 8 || (v == 16 && cfg->ndim == 2)) ctx->tune.ty = v;
         }
     }
+    // 2-D fp32 grids: advance FUSED2D_STEPS time steps per launch (fwi_fused2d.hip) whenever the step
+    // count allows it (FWI_NO_FUSED2D is the tuning / comparison hook)
+    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !getenv("FWI_NO_FUSED2D");
     int rc = create_impl(ctx);
+    if (rc == FWI_OK && ctx->fused2d) {
+        for (int i = 0; i < 2 && rc == FWI_OK; ++i) {
+            if (hipMalloc(&ctx->fx[i], (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
+                hipMemset(ctx->fx[i], 0, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess)
+                rc = ctx->fail(FWI_ENOMEM, "allocating the fused 2-D buffer pair failed");
+        }
+    }
     if (rc) {
         g_create_error = "fwi_create: " + ctx->err;
         fwi_destroy(ctx);
@@ -778,10 +1018,11 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
                     ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series, ctx->wav, ctx->snap, ctx->fwd[0],
-                    ctx->fwd[1]};
+                    ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1]};
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
-                        ps->s_cq, ps->s_col})
+                        ps->s_cq, ps->s_col, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,
+                        ps->fi_cidx, ps->fi_cu, ps->fi_cq, ps->fr_start, ps->fr_lz, ps->fr_lx, ps->fr_col})
             if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

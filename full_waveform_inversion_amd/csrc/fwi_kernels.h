@@ -101,6 +101,37 @@ hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);
 
+// ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
+constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch
+constexpr int FUSED2D_TILE = 64;   // interior tile edge (points); extended edge = TILE + 2 STEPS r
+
+struct Fused2dArgs {
+    const float *u_cur, *u_prev, *C;   // padded inputs: u^n, u^{n-1}, dt^2 c^2
+    float *out_cur, *out_prev;         // padded outputs: u^{n+K}, u^{n+K-1} (a different buffer pair)
+    const float *dz, *dx;              // damping profiles
+    float ck[5];
+    int damp;
+    int mode;                          // 0 plain, 1 store q (SAVE_Q), 2 imaging against stored q (IMAGE)
+    float *q_base;                     // q of step n lives at q_base + n * npts (compact)
+    float *g;                          // compact gradient accumulator (mode 2)
+    int n0, dn;                        // first step index of the launch and +1 / -1
+    // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
+    const int *inj_start, *inj_lz, *inj_lx, *inj_col;
+    const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)
+    const int64_t *inj_cidx;
+    const float *inj_cu, *inj_cq;
+    const float *inj_amp;               // (nt, ninj) amplitudes, row n used by step n
+    int ninj;
+    // sampling entries, sorted by tile: points in the tile's interior
+    const int *rec_start, *rec_lz, *rec_lx, *rec_col;
+    float *rec_out;                     // (nt, nrec), row n written by step n
+    float rec_scale;
+    int nrec;
+};
+
+int fused2d_num_tiles(const GridDesc &g);
+hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
+
 // optimiser vector algebra: y = a x + b y; clamp; *out = max(*out, max|x|) (out zeroed by the caller)
 template <typename T>
 hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStream_t s);

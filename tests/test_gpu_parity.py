@@ -308,25 +308,35 @@ def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
     assert log[-1]["f"] < 0.6 * log[0]["f"], log
 
 
-def test_2d_tile_kernel_matches_point_kernel(gpu):
-    """2-D: the LDS-tiled float4 kernel against the one-thread-per-point kernel, ragged rows."""
-    w = workloads.cfg2(0.13)  # 133 x 133 -> nx % 4 != 0 falls back; use an explicit shape instead
+def test_2d_kernels_agree(gpu, monkeypatch):
+    """2-D: one-thread-per-point, LDS-tiled float4 and 4-steps-per-launch fused kernels on the same
+    inputs: ragged rows, two x tiles, sources near a corner and near tile seams, damping on."""
     rng = np.random.default_rng(5)
-    shape = (133, 260)  # rows not a multiple of the tile, two x tiles
+    shape = (133, 260)
     c = 1500.0 + 1500.0 * rng.random(shape)
     dt = 0.7 * fo.cfl_dt(c.max(), 5.0, 2, 8)
     nt = 120
-    src = np.array([[60, 130], [3, 3]])
-    rec = np.stack([rng.integers(0, s, 40) for s in shape], 1)
-    wav = np.stack([fo.ricker(nt, dt, 25.0), fo.ricker(nt, dt, 15.0)], 1)
-    a = run_gpu(c, 5.0, dt, 8, 12, 900.0, src, wav, rec, residual=None, kernel="point")
-    b = run_gpu(c, 5.0, dt, 8, 12, 900.0, src, wav, rec, residual=None, kernel="stream")
-    assert a["kernel"] == "step_point" and b["kernel"] == "step2d_tile"
-    assert rel(b["seis"], a["seis"]) < 2e-6
-    assert w.ndim == 2
+    src = np.array([[60, 130], [3, 3], [63, 64]])
+    rec = np.stack([rng.integers(0, s, 60) for s in shape], 1)
+    rec[:3] = [[63, 63], [64, 64], [132, 259]]
+    wav = np.stack([fo.ricker(nt, dt, 25.0), fo.ricker(nt, dt, 15.0), -fo.ricker(nt, dt, 20.0)], 1)
+    res = rng.standard_normal((nt, 60))
+    out = {}
+    for name, kern, nofuse in (("point", "point", "1"), ("tile", "stream", "1"), ("fused", "stream", None)):
+        if nofuse:
+            monkeypatch.setenv("FWI_NO_FUSED2D", nofuse)
+        else:
+            monkeypatch.delenv("FWI_NO_FUSED2D", raising=False)
+        out[name] = run_gpu(c, 5.0, dt, 8, 12, 900.0, src, wav, rec, residual=res, kernel=kern)
+    assert [out[k]["kernel"] for k in ("point", "tile", "fused")] == ["step_point", "step2d_tile", "step2d_fused"]
+    for k in ("tile", "fused"):
+        assert rel(out[k]["seis"], out["point"]["seis"]) < 2e-6
+        assert rel(out[k]["adj_src"], out["point"]["adj_src"]) < 2e-6
+        assert rel(out[k]["grad_c"], out["point"]["grad_c"]) < 5e-6
 
 
-@pytest.mark.parametrize("shape,K", [((40, 36, 44), 7), ((40, 36, 44), 1), ((40, 36, 44), 500), ((96, 100), 16)])
+@pytest.mark.parametrize("shape,K", [((40, 36, 44), 7), ((40, 36, 44), 1), ((40, 36, 44), 500), ((96, 100), 16),
+                                     ((96, 100), 7), ((96, 100), 8)])
 def test_checkpointed_gradient_equals_store_all(gpu, shape, K):
     """SURVEY s.8f-3: snapshots every K steps + recomputation give the store-all gradient
     (K not dividing nt, K = 1, K > nt; 3-D stream kernel and 2-D tile kernel)."""
@@ -334,7 +344,7 @@ def test_checkpointed_gradient_equals_store_all(gpu, shape, K):
     nd = len(shape)
     c = 1800.0 + 1200.0 * rng.random(shape)
     dt = 0.7 * fo.cfl_dt(c.max(), 8.0, nd, 8)
-    nt = 90
+    nt = 92  # a multiple of 4: 2-D contexts take the fused path when K is one too (16, 8), not for K = 7
     src = np.array([[s // 2 for s in shape], [s // 3 for s in shape]])
     rec = np.stack([rng.integers(0, s, 17) for s in shape], 1)
     wav = np.stack([fo.ricker(nt, dt, 22.0), -0.5 * fo.ricker(nt, dt, 16.0)], 1).astype(np.float32)
