@@ -332,7 +332,7 @@ def test_2d_kernels_agree(gpu, monkeypatch):
     for k in ("tile", "fused"):
         assert rel(out[k]["seis"], out["point"]["seis"]) < 2e-6
         assert rel(out[k]["adj_src"], out["point"]["adj_src"]) < 2e-6
-        assert rel(out[k]["grad_c"], out["point"]["grad_c"]) < 5e-6
+        assert rel(out[k]["grad_c"], out["point"]["grad_c"]) < 1e-5
 
 
 @pytest.mark.parametrize("shape,K", [((40, 36, 44), 7), ((40, 36, 44), 1), ((40, 36, 44), 500), ((96, 100), 16),

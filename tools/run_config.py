@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--iters", type=int, default=0, help="L-BFGS iterations; 0 = one gradient only")
     ap.add_argument("--host-lbfgs", action="store_true", help="keep the optimiser vectors on the host")
     ap.add_argument("--pool", type=int, default=0,
-                    help="engines sharing this GPU's shots concurrently; 0 = auto (4 in 2-D, 1 in 3-D)")
+                    help="engines sharing this GPU's shots concurrently; 0 = auto (2 in 2-D, 1 in 3-D)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -35,7 +35,7 @@ def main():
     w = workloads.CONFIGS[a.config](a.scale, **kw)
     wav = w.wavelet()
     shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(len(w.src_idx))]
-    psize = a.pool or (4 if w.ndim == 2 else 1)
+    psize = a.pool or (2 if w.ndim == 2 else 1)
     from full_waveform_inversion_amd import default_sigma_max
     sigma = default_sigma_max(float(w.c.max()), w.h, w.npml)
     pool = sh.EnginePool(lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
