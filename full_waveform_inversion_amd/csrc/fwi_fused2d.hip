@@ -35,12 +35,14 @@ __device__ __forceinline__ float rcp1(float a) {
 }  // namespace
 
 // Tile geometry: interior FT x FT points, KS fused steps, radius R  ->  extended edge FT + 2 KS R.
-// 512 threads (2 waves per SIMD) measured 4.3 vs 5.5 us/step for 256; the kernel is bounded by its
-// instruction stream (~230 instructions per float4 group and sub-step), not by LDS or memory.
-constexpr int FNT = 512;  // threads per workgroup
-
+// Threads per workgroup (one workgroup per CU: the two LDS images take 74 KB).  PMC profile at 512:
+// 57 % of the wave cycles are waits (LDS round trips, three barriers per sub-step, the initial
+// global loads), the rest ~2400 instructions per wave.  Measured at 1024^2, us/step: 256 threads
+// 5.5, 512 4.1, 1024 3.85 (forward); the imaging variant spills at the 128-VGPR cap of 1024
+// threads and stays at 512 (5.5 vs 5.8).
 template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE>
-__global__ __launch_bounds__(FNT) void step2d_fused(Fused2dArgs a, GridDesc g) {
+__global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
+    constexpr int FNT = IMAGE ? 512 : 1024;
     constexpr int HL = KS * R;           // halo cells per side
     constexpr int E = FT + 2 * HL;       // extended tile edge (rows and columns)
     constexpr int E4 = E / 4;            // float4 groups per row
@@ -274,13 +276,13 @@ int fused2d_num_tiles(const GridDesc &g) {
 template <int R, bool DAMP>
 static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
     constexpr int KS = FUSED2D_STEPS, FT = FUSED2D_TILE;
-    const dim3 grid(fused2d_num_tiles(g)), block(FNT);
+    const dim3 grid(fused2d_num_tiles(g));
     if (a.mode == 1)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false>), grid, dim3(1024), 0, s, a, g);
     else if (a.mode == 2)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true>), grid, dim3(512), 0, s, a, g);
     else
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false>), grid, block, 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false>), grid, dim3(1024), 0, s, a, g);
     return hipGetLastError();
 }
 
