@@ -463,3 +463,39 @@ def test_gpu_fp64_adjoint_identity(gpu, shape):
         a = e.adjoint(r, image=False)
     lhs, rhs = float(np.sum(d * r)), float(np.sum(w * a))
     assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs))
+
+
+def test_random_small_configurations_fuzz(gpu):
+    """Seeded fuzz over small odd grids (narrower than a tile, thinner than the stencil, borders as
+    wide as the grid allows), all orders, 2-D / 3-D, fp32: forward + adjoint + gradient vs the C oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        nd = int(rng.integers(2, 4))
+        order = int(rng.choice([2, 4, 8]))
+        shape = tuple(int(rng.integers(3, 41)) for _ in range(nd))
+        if rng.random() < 0.5:  # make the float4 kernels eligible
+            shape = shape[:-1] + (4 * int(rng.integers(1, 12)),)
+        npml = int(rng.integers(0, max(1, min(shape) // 2)))
+        nt = int(rng.choice([7, 8, 12, 16, 21]))
+        c = 1500.0 + 2000.0 * rng.random(shape)
+        dt = 0.6 * fo.cfl_dt(c.max(), 6.0, nd, order)
+        nsrc, nrec = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+        src = np.stack([rng.integers(0, s, nsrc) for s in shape], 1)
+        rec = np.stack([rng.integers(0, s, nrec) for s in shape], 1)
+        w = rng.standard_normal((nt, nsrc))
+        r = rng.standard_normal((nt, nrec))
+        p = CPropagator(c, 6.0, dt, order, npml)
+        d = p.forward(src, w, rec)
+        a = p.adjoint(r)
+        g = p.gradient()
+        ck = int(rng.choice([0, 0, 4, 5]))
+        with Engine(shape, 6.0, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, ckpt_interval=ck) as e:
+            dg = e.forward(c, (src, w), rec, save=True)
+            ag = e.adjoint(r)
+            gg = e.gradient()
+            kern = e.kernel_name
+        tag = (case, shape, order, npml, nt, ck, kern)
+        scale = max(np.linalg.norm(d), 1e-300)
+        assert np.linalg.norm(dg - d) < 2e-5 * scale, tag
+        assert np.linalg.norm(ag - a) < 2e-5 * max(np.linalg.norm(a), 1e-300), tag
+        assert np.linalg.norm(gg - g) < 5e-5 * max(np.linalg.norm(g), 1e-300), tag
