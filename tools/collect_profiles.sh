@@ -1,5 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/final
+rm -rf gpurun_out/final; mkdir -p gpurun_out/final
 R=$GRAFT_REPO_ROOT
 python tools/parity_report.py gpurun_out/final/parity.json > gpurun_out/final/parity.log 2>&1; tail -3 gpurun_out/final/parity.log | cut -c1-200
 python bench.py > gpurun_out/final/bench_forward.json 2> gpurun_out/final/bench_forward.err; tail -1 gpurun_out/final/bench_forward.json | cut -c1-200
@@ -15,3 +15,5 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_ou
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/ktgrad -- python3 $R/bench.py --mode gradient --steps 1 --warmup 1 > /dev/null 2>&1
 cd $R; python tools/bench_mc.py --cpu-samples 100 > gpurun_out/final/mc.jsonl 2>/dev/null
 ls gpurun_out/final/*/*/ | head -40
+cd /tmp && timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/kt2d -- python3 $R/tools/time_config.py --config cfg2 --nt 1000 --rounds 1 > $R/gpurun_out/final/time2d.log 2>&1
+cd $R
