@@ -13,6 +13,9 @@ constexpr int HALO = 4;
 // the allocation: x to XALIGN cells, y to YALIGN rows.
 constexpr int XALIGN = 256;
 constexpr int YALIGN = 16;
+// Zero planes appended behind the far z halo of 3-D fields: the stream kernel reads up to
+// r + PF (<= 4 + 3) planes past the last interior plane without clamping.
+constexpr int LOOKAHEAD = 4;
 
 // Padded field geometry.  Element (z, y, x) of the interior lives at
 // off0 + z*sz + y*sy + x.  2-D grids are ny = 1 with no y halo (sz == sy).

@@ -33,8 +33,10 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     const int64_t py = (ndim == 3) ? HALO + round_up(g.ny, YALIGN) + HALO : 1;
     g.sz = g.sy * py;
     g.off0 = (int64_t)HALO * g.sz + (int64_t)hy * g.sy + HALO;
-    // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D
-    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz) + 2 * HALO);
+    // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D.
+    // 3-D: LOOKAHEAD extra zero planes behind the far z halo, so the stream kernel's prefetches of
+    // planes z + r + 1 ... need no clamping (affine addresses: the plane offsets strength-reduce).
+    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO);
     g.npts = (int64_t)nz * g.ny * nx;
     return g;
 }
@@ -218,7 +220,6 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     const int z1 = min(g.nz, z0 + zchunk);
     const bool act = FULL || ((x0 < g.nx) && (y < g.ny));
     const int64_t sz = g.sz, sy = g.sy;
-    const int zlast = g.nz + HALO - 1;  // last padded plane (interior-relative)
 
     // Addressing: wave-uniform 64-bit plane base (SGPRs) + per-thread 32-bit
     // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TX);
     const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : poff;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
-    const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : (HV + lane) * VL;
+    // idle lanes write consecutive words of the trash row (a 16 B stride would be a 4-way bank conflict)
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : lane;
 
     // loop-invariant xy part of the damping
     V Axy, Bxy, dxy;
@@ -279,19 +281,19 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     constexpr int NRH = HPF + 1;
     V zq[NQ];
 #pragma unroll
-    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)min(z0 - R + k, zlast) * sz + poff);
+    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
     V up[NR], Cc[NR], halo[NRH][NH];
     T edge[NR];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-        const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
+        const int64_t o = (int64_t)(z0 + p) * sz;
         up[p] = ldv<T>(a.u_prev + o + poff);
         Cc[p] = ldv<T>(a.C + o + poff);
         edge[p] = a.u_cur[o + eoff];
     }
 #pragma unroll
     for (int p = 0; p < HPF; ++p) {
-        const int64_t o = (int64_t)min(z0 + p, zlast) * sz;
+        const int64_t o = (int64_t)(z0 + p) * sz;
 #pragma unroll
         for (int i = 0; i < NH; ++i) halo[p][i] = ldv<T>(a.u_cur + o + hoff[i]);
     }
@@ -313,10 +315,10 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             reinterpret_cast<T *>(&L[erow][0])[ecol] = edge[cur];
 
             // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
-            const int64_t on = (int64_t)min(z + PF, zlast) * sz;
-            zq[(ph + 2 * R + PF) % NQ] = ldv<T>(a.u_cur + (int64_t)min(z + R + PF, zlast) * sz + poff);
+            const int64_t on = (int64_t)(z + PF) * sz;
+            zq[(ph + 2 * R + PF) % NQ] = ldv<T>(a.u_cur + (int64_t)(z + R + PF) * sz + poff);
             {
-                const int64_t oh = (int64_t)min(z + HPF, zlast) * sz;
+                const int64_t oh = (int64_t)(z + HPF) * sz;
 #pragma unroll
                 for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ldv<T>(a.u_cur + oh + hoff[i]);
             }
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     const int64_t rowoff = g.off0 + (int64_t)z * sz + bx * TILE_X;
     const int64_t eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
-    const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : 4 + 4 * lane;
+    const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : lane;
     const float edge = a.u_cur[eoff];
     const f4 up = ld4(a.u_prev + poff), Cc = ld4(a.C + poff);
     const int64_t ci = (int64_t)z * g.nx + x0;
