@@ -1295,9 +1295,9 @@ int fwi_synchronize(fwi_ctx *ctx) {
 // The reference's real hot loop: batched scoring of source samples.
 // ---------------------------------------------------------------------------------------------
 namespace fwi {
-hipError_t launch_mc_score(const double *G, const double *d, const double *Ms, const double *dmom, int k, int n,
-                           int t, int64_t nsamp, int metric, int normalise, int all_at_once, double gau_sigma,
-                           double *sim, double *like, hipStream_t s);
+hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,
+                           int k, int n, int t, int64_t nsamp, int metric, int normalise, int all_at_once,
+                           double gau_sigma, double *sim, double *like, hipStream_t s);
 hipError_t launch_mc_forward(const double *G, const double *Ms, int k, int n, int t, int64_t nsamp, double *synth,
                              hipStream_t s);
 size_t mc_score_lds_bytes(int k, int n);
@@ -1385,9 +1385,23 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
         sigma = (hi > lo) ? acc / (double)(hi - lo) : NAN;
     }
     hipStream_t s = nullptr;  // default stream: this call is synchronous
-    DevBuf G, d, M, dm, sim, like;
+    DevBuf G, Gt, d, M, dm, sim, like;
+    const size_t mc_pad = 1024;  // bytes of zero padding behind Gt and d (>= 2 pipelined groups of 9 doubles)
     const size_t gb = (size_t)k * n * t * 8, db = (size_t)k * t * 8, mb = (size_t)n * nsamp * 8, sb = (size_t)nsamp * 8;
     MCCHK(hipMalloc(&G.p, gb));
+    if (n == 3 || n == 6 || n == 9) {  // packed [k][t][n + 1] stream for the lane-per-sample kernel's scalar loads
+        const size_t row = (size_t)n + 1, pb = (size_t)k * t * row * 8;
+        std::vector<double> gt((size_t)k * t * row);
+        for (int kk = 0; kk < k; ++kk)
+            for (int e = 0; e < t; ++e) {
+                double *r = &gt[((size_t)kk * t + e) * row];
+                for (int j = 0; j < n; ++j) r[j] = green[((size_t)kk * n + j) * t + e];
+                r[n] = data[(size_t)kk * t + e];
+            }
+        MCCHK(hipMalloc(&Gt.p, pb + mc_pad));  // the kernel's look-ahead reads a few rows past the end
+        MCCHK(hipMemcpy(Gt.p, gt.data(), pb, hipMemcpyHostToDevice));
+        MCCHK(hipMemset((char *)Gt.p + pb, 0, mc_pad));
+    }
     MCCHK(hipMalloc(&d.p, db));
     MCCHK(hipMalloc(&M.p, mb));
     MCCHK(hipMalloc(&dm.p, dmom.size() * 8));
@@ -1401,7 +1415,7 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
     MCCHK(hipEventCreate(&e0));
     MCCHK(hipEventCreate(&e1));
     MCCHK(hipEventRecord(e0, s));
-    hipError_t le = fwi::launch_mc_score((const double *)G.p, (const double *)d.p, (const double *)M.p,
+    hipError_t le = fwi::launch_mc_score((const double *)G.p, (const double *)Gt.p, (const double *)d.p, (const double *)M.p,
                                          (const double *)dm.p, k, n, t, nsamp, metric, normalise != 0,
                                          all_at_once != 0, sigma, (double *)sim.p, (double *)like.p, s);
     if (le != hipSuccess) return mc_fail(FWI_EHIP, "mc_score_kernel launch", le);

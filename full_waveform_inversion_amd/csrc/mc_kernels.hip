@@ -254,6 +254,204 @@ __global__ __launch_bounds__(MC_THREADS) void mc_score_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lane-per-sample kernel (n = 3 / 6 / 9): every lane scores ONE sample, marching through all
+// (trace, time) pairs itself.  The Green's function column of a time sample is the same for all
+// lanes, so it comes through the scalar path (G is repacked [k][t][n] on the host: one contiguous
+// scalar load per time sample) and enters v_fma_f64 as an SGPR operand; the per-trace moments
+// live in the lane's registers and are folded into the metric at the end of each trace.  No LDS,
+// no shuffles, no barriers: the kernel is pure fp64 FMA work (13 VALU per sample-time-sample).
+// ---------------------------------------------------------------------------------------------
+// Two consecutive rows of the packed stream Gd[k][t][NC + 1] (row = g_0 .. g_{NC-1}, d) held in
+// SGPRs.  The loads are issued by hand: hipcc sinks compiler-visible scalar loads down to their
+// first use, which exposes the scalar-cache miss latency of every group; here the next group's
+// s_load is in flight while the current group's FMAs issue, and fence() is the matching
+// s_waitcnt (SMEM returns out of order, so lgkmcnt(0) is the only usable count).  `pin` is a VGPR
+// every FMA chain starts from (M[0]): routing it through the asm keeps the scheduler from hoisting
+// the previous group's chains below the load or this group's above it.
+typedef double sd8 __attribute__((ext_vector_type(8)));
+typedef double sd4 __attribute__((ext_vector_type(4)));
+typedef double sd2 __attribute__((ext_vector_type(2)));
+constexpr int MC_LANES_UNROLL = 2;  // rows per group; the stream carries >= 3 groups of zero padding
+template <int NC>
+struct McStage;
+template <>
+struct McStage<9> {  // 20 doubles = 8 + 8 + 4
+    sd8 a, b;
+    sd4 c;
+    __device__ __forceinline__ void load(const double *p, double &pin) {
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx8 %2, %4, 0x80"
+                     : "=&s"(a), "=&s"(b), "=&s"(c), "+v"(pin) : "s"(p) : "memory");
+    }
+    __device__ __forceinline__ void fence() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)); }
+    __device__ __forceinline__ double at(int i) const { return i < 8 ? a[i] : i < 16 ? b[i - 8] : c[i - 16]; }
+};
+template <>
+struct McStage<6> {  // 14 doubles = 8 + 4 + 2
+    sd8 a;
+    sd4 b;
+    sd2 c;
+    __device__ __forceinline__ void load(const double *p, double &pin) {
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x40\n\ts_load_dwordx4 %2, %4, 0x60"
+                     : "=&s"(a), "=&s"(b), "=&s"(c), "+v"(pin) : "s"(p) : "memory");
+    }
+    __device__ __forceinline__ void fence() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)); }
+    __device__ __forceinline__ double at(int i) const { return i < 8 ? a[i] : i < 12 ? b[i - 8] : c[i - 12]; }
+};
+template <>
+struct McStage<3> {  // 8 doubles
+    sd8 a;
+    __device__ __forceinline__ void load(const double *p, double &pin) {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=&s"(a), "+v"(pin) : "s"(p) : "memory");
+    }
+    __device__ __forceinline__ void fence() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+    __device__ __forceinline__ double at(int i) const { return a[i]; }
+};
+
+template <bool LAG, int NC>
+__global__ __launch_bounds__(256) void mc_score_lanes(const double *__restrict__ Gd, const double *__restrict__ Ms,
+                                                      const double *__restrict__ dmom, int k, int t, int64_t nsamp,
+                                                      int metric, int normalise, int all_at_once,
+                                                      double gau_sigma, double *__restrict__ sim_out,
+                                                      double *__restrict__ like_out) {
+    constexpr int U = MC_LANES_UNROLL, ROW = NC + 1;
+    const int64_t smp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t sc = smp < nsamp ? smp : nsamp - 1;
+    double M[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) M[j] = Ms[(int64_t)j * nsamp + sc];  // reference layout MTs[:, i]
+
+    const double L = (double)t;
+    double acc = 0.0, num = 0.0, den = 0.0;
+    SeqMom tot = {0, 0, 0, 0, 0, 0};
+    double prev_dl = 0.0, prev_sl = 0.0;
+    double first_sf = 0.0, first_b = 1.0, last_sl = 0.0;  // normalised first / last synthetic samples
+    for (int kk = 0; kk < k; ++kk) {
+        const double *g = Gd + (int64_t)kk * t * ROW;
+        double a1 = 0.0, a2 = 0.0, ads = 0.0, amx = 0.0, ass1 = 0.0, ads1 = 0.0, ad1s = 0.0;
+        double sprev = 0.0, dprev = 0.0, sv = 0.0;
+        // one time sample: synthetic value (same j order as the reference) and its moments
+        auto sample = [&](auto gv, double dv, bool first) __attribute__((always_inline)) {
+            sv = 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) sv += gv(j) * M[j];
+            a1 += sv;
+            a2 += sv * sv;
+            ads += dv * sv;
+            amx = fmax(amx, fabs(sv));
+            if (LAG) {
+                if (!first) {
+                    ass1 += sprev * sv;
+                    ads1 += dprev * sv;
+                    ad1s += dv * sprev;
+                }
+                sprev = sv;
+                dprev = dv;
+            }
+        };
+        auto group = [&](const McStage<NC> &st) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) sample([&](int j) { return st.at(u * ROW + j); }, st.at(u * ROW + NC), false);
+        };
+        auto plain = [&](int e, bool first) __attribute__((always_inline)) {
+            const double *r = g + (int64_t)e * ROW;
+            sample([&](int j) { return r[j]; }, r[NC], first);
+        };
+        // sample 0 apart (it has no lag partner and is the "first" boundary value) ...
+        plain(0, true);
+        const double sfirst = sv;
+        // ... then groups of U rows through two SGPR stages in ping-pong
+        int e = 1;
+        const int ngroups = (t - 1) / U;
+        McStage<NC> A, B;
+        A.load(g + (int64_t)e * ROW, M[0]);
+        A.fence();
+        int gi = 0;
+        for (; gi + 2 <= ngroups; gi += 2) {
+            B.load(g + (int64_t)(e + U) * ROW, M[0]);
+            group(A);
+            B.fence();
+            A.load(g + (int64_t)(e + 2 * U) * ROW, M[0]);  // may run into the next trace / the padding
+            group(B);
+            A.fence();
+            e += 2 * U;
+        }
+        if (gi < ngroups) {
+            group(A);
+            e += U;
+        }
+        for (; e < t; ++e) plain(e, false);
+        const double slast = sv;
+        // ---- fold this trace into the metric (same closed forms as the moment kernel above) ----
+        const double *dm = dmom + (size_t)kk * NDMOM;
+        const double a = normalise ? 1.0 / dm[D_MAX] : 1.0;
+        const double b = normalise ? 1.0 / amx : 1.0;
+        const double dd = a * a * dm[D_2], ss = b * b * a2, ds = a * b * ads;
+        const double d1 = a * dm[D_1], s1 = b * a1;
+        const double res = dd - 2.0 * ds + ss;
+        if (metric == MC_VR) {
+            if (all_at_once) { num += res; den += dd; }
+            else { const double vr = 1.0 - res / dd; acc += vr < 0.0 ? 0.0 : vr; }
+        } else if (metric == MC_GAU) {
+            num += res;
+        } else if (metric == MC_CC || metric == MC_PCC) {
+            if (all_at_once) { tot.sx += d1; tot.sy += s1; tot.sxx += dd; tot.syy += ss; tot.sxy += ds; tot.len += L; }
+            else { SeqMom q = {d1, s1, dd, ss, ds, L}; acc += corr_from(q); }
+        } else {
+            const double df = a * dm[D_FIRST], dl = a * dm[D_LAST], sf = b * sfirst, sl = b * slast;
+            const double dd1 = a * a * dm[D_DD1], ss1 = b * b * ass1;
+            const double ds1 = a * b * ads1, d1s = a * b * ad1s;
+            if (!all_at_once) {
+                SeqMom q;
+                q.len = 4.0 * L;
+                q.sx = up_sum(d1, df, dl);
+                q.sy = up_sum(s1, sf, sl);
+                q.sxx = up_dot(dd, dd1, dd1, df * df, dl * dl);
+                q.syy = up_dot(ss, ss1, ss1, sf * sf, sl * sl);
+                q.sxy = up_dot(ds, ds1, d1s, df * sf, dl * sl);
+                acc += corr_from(q);
+            } else {
+                tot.sx += d1; tot.sy += s1; tot.sxx += dd; tot.syy += ss; tot.sxy += ds; tot.len += L;
+                num += dd1 + (kk ? prev_dl * df : 0.0);
+                den += ss1 + (kk ? prev_sl * sf : 0.0);
+                acc += ds1 + d1s + (kk ? prev_dl * sf + prev_sl * df : 0.0);
+                prev_dl = dl; prev_sl = sl;
+                if (kk == 0) { first_sf = sf; first_b = b; }
+                last_sl = sl;
+            }
+        }
+    }
+    (void)first_b;
+    double sim;
+    if (metric == MC_VR) {
+        if (all_at_once) { sim = 1.0 - num / den; sim = sim < 0.0 ? 0.0 : sim; }
+        else sim = acc / k;
+    } else if (metric == MC_GAU) {
+        sim = all_at_once ? exp(-num / (2.0 * gau_sigma * gau_sigma)) : 0.0;
+    } else if (metric == MC_CC || metric == MC_PCC) {
+        sim = all_at_once ? corr_from(tot) : acc / k;
+    } else if (!all_at_once) {
+        sim = acc / k;
+    } else {
+        const double a0 = normalise ? 1.0 / dmom[D_MAX] : 1.0;
+        const double aL = normalise ? 1.0 / dmom[(size_t)(k - 1) * NDMOM + D_MAX] : 1.0;
+        const double df = a0 * dmom[D_FIRST], sf = first_sf;
+        const double dl = aL * dmom[(size_t)(k - 1) * NDMOM + D_LAST], sl = last_sl;
+        SeqMom q;
+        q.len = 4.0 * tot.len;
+        q.sx = up_sum(tot.sx, df, dl);
+        q.sy = up_sum(tot.sy, sf, sl);
+        q.sxx = up_dot(tot.sxx, num, num, df * df, dl * dl);
+        q.syy = up_dot(tot.syy, den, den, sf * sf, sl * sl);
+        q.sxy = 1.875 * (tot.sxy - dl * sl) + 0.875 * (tot.sxy - df * sf) + 0.625 * acc + 4.0 * dl * sl;
+        sim = corr_from(q);
+    }
+    if (smp < nsamp) {
+        sim_out[smp] = sim;
+        if (like_out) like_out[smp] = exp(-(1.0 - sim) / 2.0);  // :774
+    }
+}
+
 // forward_model for a batch: synth[i, k, t] (full_waveform_inversion.py:253-264), same j order
 __global__ void mc_forward_kernel(const double *__restrict__ G, const double *__restrict__ Ms, int k, int n,
                                   int t, int64_t nsamp, double *__restrict__ synth) {
@@ -268,9 +466,25 @@ __global__ void mc_forward_kernel(const double *__restrict__ G, const double *__
     }
 }
 
-hipError_t launch_mc_score(const double *G, const double *d, const double *Ms, const double *dmom, int k, int n,
-                           int t, int64_t nsamp, int metric, int normalise, int all_at_once, double gau_sigma,
-                           double *sim, double *like, hipStream_t s) {
+// Gt = G and d packed [k][t][n + 1] (row = g_0..g_{n-1}, d) followed by >= 1 KiB of zeros; given for
+// n = 3 / 6 / 9, which take the lane-per-sample kernel
+hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,
+                           int k, int n, int t, int64_t nsamp, int metric, int normalise, int all_at_once,
+                           double gau_sigma, double *sim, double *like, hipStream_t s) {
+    if (Gt && (n == 3 || n == 6 || n == 9)) {
+        const unsigned blocks = (unsigned)((nsamp + 255) / 256);
+        const bool lg = metric == MC_CCSHIFT;
+#define MC_LANES(LAG, NC)                                                                                \
+    hipLaunchKernelGGL((mc_score_lanes<LAG, NC>), dim3(blocks), dim3(256), 0, s, Gt, Ms, dmom, k, t, nsamp, \
+                       metric, normalise, all_at_once, gau_sigma, sim, like)
+        switch (n) {
+            case 3: if (lg) MC_LANES(true, 3); else MC_LANES(false, 3); break;
+            case 6: if (lg) MC_LANES(true, 6); else MC_LANES(false, 6); break;
+            default: if (lg) MC_LANES(true, 9); else MC_LANES(false, 9); break;
+        }
+#undef MC_LANES
+        return hipGetLastError();
+    }
     const size_t shm = ((size_t)n * SPB + (size_t)k * SPB * NMOM) * sizeof(double);
     const unsigned grid = (unsigned)((nsamp + SPB - 1) / SPB);
 #define MC_LAUNCH(LAG, NC)                                                                                  \
