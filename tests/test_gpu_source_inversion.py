@@ -72,6 +72,30 @@ def test_shipped_shape_vs_pinned_oracle(gpu, metric):
             assert np.allclose(sim, ref, rtol=TOL, atol=1e-12), (norm, allat, np.abs(sim - ref).max())
 
 
+@pytest.mark.parametrize("n", [3, 6, 9, 5])
+@pytest.mark.parametrize("t", [2, 3, 4, 5, 6, 7, 9, 33])
+def test_short_and_odd_traces_both_kernels(gpu, n, t):
+    """Group / tail handling of the lane-per-sample kernel (n = 3 / 6 / 9: two-row groups in ping-pong, so
+    every residue of (t - 1) mod 4 is hit) and the moment kernel (any other n), ragged sample counts."""
+    rng = np.random.default_rng(100 * n + t)
+    k, N = 4, 300
+    G = rng.standard_normal((k, n, t))
+    Ms = rng.standard_normal((n, N))
+    d = np.einsum("kjt,j->kt", G, Ms[:, 7]) + 0.3 * rng.standard_normal((k, t))
+    for metric in ("VR", "CC", "CC-shift", "gau"):
+        for norm, allat in ((False, False), (True, True)):
+            if metric == "gau" and not allat:
+                continue
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.array([mo.compare_synth_to_real_waveforms(d, mo.forward_model(G, Ms[:, i]), metric,
+                                                                   norm, allat) for i in range(N)])
+            for cnt in (N, 1):
+                sim = si.score_samples(d, G, Ms[:, :cnt], metric, norm, allat)[0]
+                assert np.allclose(sim, ref[:cnt], rtol=1e-8, atol=1e-11, equal_nan=True), \
+                    (metric, norm, allat, cnt, np.nanmax(np.abs(sim - ref[:cnt])))
+
+
 def test_million_samples_best_is_truth(gpu):
     """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
     rng = np.random.default_rng(0)
