@@ -86,14 +86,17 @@ def test_short_and_odd_traces_both_kernels(gpu, n, t):
         for norm, allat in ((False, False), (True, True)):
             if metric == "gau" and not allat:
                 continue
+            nref = 12 if metric == "CC-shift" else N  # the oracle's CC-shift manages ~50 samples/s
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 ref = np.array([mo.compare_synth_to_real_waveforms(d, mo.forward_model(G, Ms[:, i]), metric,
-                                                                   norm, allat) for i in range(N)])
+                                                                   norm, allat) for i in range(nref)])
             for cnt in (N, 1):
                 sim = si.score_samples(d, G, Ms[:, :cnt], metric, norm, allat)[0]
-                assert np.allclose(sim, ref[:cnt], rtol=1e-8, atol=1e-11, equal_nan=True), \
-                    (metric, norm, allat, cnt, np.nanmax(np.abs(sim - ref[:cnt])))
+                m = min(cnt, nref)
+                assert sim.shape == (cnt,)
+                assert np.allclose(sim[:m], ref[:m], rtol=1e-8, atol=1e-11, equal_nan=True), \
+                    (metric, norm, allat, cnt, np.nanmax(np.abs(sim[:m] - ref[:m])))
 
 
 def test_million_samples_best_is_truth(gpu):
