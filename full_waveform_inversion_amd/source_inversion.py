@@ -5,9 +5,8 @@ Mirrors the reference's function names and argument meaning for the source-inver
 ``compare_synth_to_real_waveforms(...)`` (:584) and the scoring part of
 ``perform_monte_carlo_sampled_waveform_inversion`` (:786).  The per-sample loop body
 (forward model + similarity + likelihood, :713-774) runs as one fused HIP kernel over all
-samples; the random source samplers (:282-510) are left to the caller (simple full-MT and
-single-force samplers are provided for convenience, using numpy's Generator, so their
-streams differ from the reference's unseeded global RNGs).  fp64 like the reference.
+samples; the seven random source samplers (:282-510) live in ``samplers.py`` (batched on the
+host, reproducing the reference's stream on request).  fp64 like the reference.
 There is no CPU fallback: without the HIP library / a GPU these raise FwiError.
 """
 from __future__ import annotations
@@ -16,7 +15,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, samplers
 
 
 def _p(a):
@@ -80,15 +79,13 @@ def compare_synth_to_real_waveforms(real_data_array, green_func_array, M, compar
 
 
 def random_full_mt(num_samples, rng):
-    """Unit 6-vectors uniform on the 5-sphere (what generate_random_MT, :282-293, produces)."""
-    v = rng.standard_normal((6, num_samples))
-    return v / np.linalg.norm(v, axis=0, keepdims=True)
+    """Unit 6-vectors uniform on the 5-sphere (generate_random_MT, :282-293)."""
+    return samplers.draw("full_mt", num_samples, rng)[0]
 
 
 def random_single_force(num_samples, rng):
     """Unit 3-vectors uniform on the sphere (generate_random_single_force_vector, :320-331)."""
-    v = rng.standard_normal((3, num_samples))
-    return v / np.linalg.norm(v, axis=0, keepdims=True)
+    return samplers.draw("single_force", num_samples, rng)[0]
 
 
 def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_array, num_samples=1000,
@@ -96,23 +93,31 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
                                                    comparison_metric="CC",
                                                    perform_normallised_waveform_inversion=True,
                                                    compare_all_waveforms_simultaneously=True, MTs=None,
-                                                   seed=0, device=0):
+                                                   seed=0, device=0, reference_stream=False,
+                                                   return_absolute_similarity_values_switch=True):
     """The reference's driver (:786-870) with the sample loop on the GPU.
 
-    ``MTs (n, N)`` may be supplied (e.g. drawn by the reference's own samplers); otherwise
-    ``full_mt`` / ``single_force`` samples are drawn here.  Returns ``(MTs, MTp, MTp_absolute)``
-    like the reference: samples, posterior ``L / sum L`` and the likelihoods ``exp(-(1-s)/2)``.
+    ``inversion_type`` is any of the reference's seven (:740-760): ``full_mt``, ``DC``,
+    ``single_force``, ``DC_single_force_couple``, ``DC_single_force_no_coupling``,
+    ``DC_crack_couple``, ``single_force_crack_no_coupling``; samples are drawn by ``samplers.draw``
+    from ``default_rng(seed)``, or -- ``reference_stream=True`` -- from the global ``numpy.random`` /
+    ``random`` generators in the reference's order, which reproduces a one-process run of the
+    reference seeded the same way.  ``MTs (n, N)`` may be supplied instead.
+
+    Returns ``(MTs, MTp, MTp_absolute)`` like the reference: the samples (scaled by ``M_amplitude``,
+    with the sampler's amplitude fraction appended as an extra row for the four coupled types,
+    :852-853), the posterior ``L / sum L`` (:847-848) and the likelihoods ``exp(-(1-s)/2)`` (:774;
+    ``[]`` when ``return_absolute_similarity_values_switch`` is false, :866-869).
     """
+    frac = None
     if MTs is None:
-        rng = np.random.default_rng(seed)
-        if inversion_type == "full_mt":
-            MTs = random_full_mt(num_samples, rng) * M_amplitude
-        elif inversion_type == "single_force":
-            MTs = random_single_force(num_samples, rng) * M_amplitude
-        else:
-            raise ValueError("built-in samplers cover 'full_mt' and 'single_force'; pass MTs for %r"
-                             % inversion_type)
+        rng = None if reference_stream else np.random.default_rng(seed)
+        MTs, frac = samplers.draw(inversion_type, num_samples, rng, reference_stream)
+        MTs = MTs * M_amplitude
+    MTs = _f64(MTs)
     _, like, post = score_samples(real_data_array, green_func_array, MTs, comparison_metric,
                                   perform_normallised_waveform_inversion,
                                   compare_all_waveforms_simultaneously, device)
-    return np.asarray(MTs, float), post, like
+    if frac is not None:
+        MTs = np.vstack((MTs, frac))
+    return MTs, post, (like if return_absolute_similarity_values_switch else [])

@@ -13,6 +13,11 @@ compare_synth_to_real_waveforms (:584-684, all 5 metrics x 4 dispatcher modes), 
 map exp(-(1-s)/2) (:774) and the posterior normalisation (:847-848) through
 perform_monte_carlo_sampled_waveform_inversion (:786) run with one process and fixed seeds.
 
+ref_samplers.npz pins the seven samplers (:282-510) and the driver's handling of every
+inversion_type (:740-760, :852-853): after np.random.seed(s); random.seed(s) each sampler is
+called 48 times and its outputs kept, and the one-process driver is run per type on a small
+seeded problem.
+
 Run from the repo root (only where /root/reference exists):
     python tests/golden/make_reference_golden.py
 """
@@ -91,8 +96,54 @@ def case(ref, name, seed, k, n, t, nsamp, inversion_type):
     print(name, "k,n,t =", (k, n, t), "samples", nsamp, "VR(truth, per-trace) =", out["sim_VR_n0_a0"][-1])
 
 
+SAMPLERS = {"full_mt": "generate_random_MT", "DC": "generate_random_DC_MT",
+            "single_force": "generate_random_single_force_vector",
+            "DC_single_force_couple": "generate_random_DC_single_force_coupled_tensor",
+            "DC_single_force_no_coupling": "generate_random_DC_single_force_uncoupled_tensor",
+            "DC_crack_couple": "generate_random_DC_crack_coupled_tensor",
+            "single_force_crack_no_coupling": "generate_random_single_force_crack_uncoupled_tensor"}
+
+
+def samplers_case(ref, name, nsamp=48, ndrv=40):
+    out = {}
+    for idx, (typ, fn) in enumerate(SAMPLERS.items()):
+        seed = 1000 + idx
+        np.random.seed(seed)
+        random.seed(seed)
+        cols, fracs = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(nsamp):
+                r = getattr(ref, fn)()
+                if isinstance(r, tuple):
+                    cols.append(r[0])
+                    fracs.append(r[1])
+                else:
+                    cols.append(r)
+        out["seed_" + typ] = seed
+        out["M_" + typ] = np.hstack(cols)
+        if fracs:
+            out["frac_" + typ] = np.array(fracs)
+        # the driver for this type (one process): MTs incl. the amplitude-fraction row, posterior, likelihoods
+        n = out["M_" + typ].shape[0]
+        G, d, _ = make_inputs(50 + idx, 4, n, 64)
+        np.random.seed(seed + 7)
+        random.seed(seed + 7)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            MTs, MTp, MTp_abs = ref.perform_monte_carlo_sampled_waveform_inversion(
+                d, G, num_samples=ndrv, M_amplitude=0.7, inversion_type=typ, comparison_metric="PCC",
+                perform_normallised_waveform_inversion=True, compare_all_waveforms_simultaneously=False,
+                num_processors=1, return_absolute_similarity_values_switch=True)
+        out["drv_G_" + typ], out["drv_d_" + typ] = G, d
+        out["drv_MTs_" + typ], out["drv_MTp_" + typ], out["drv_MTp_absolute_" + typ] = MTs, MTp, MTp_abs
+        print(typ, "samples", out["M_" + typ].shape, "driver MTs", MTs.shape)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
     ref = load_reference()
+    samplers_case(ref, "ref_samplers")
     case(ref, "ref_mc_fullmt", 0, 5, 6, 160, 24, "full_mt")
     case(ref, "ref_mc_force", 1, 21, 3, 100, 16, "single_force")
     case(ref, "ref_mc_dc", 2, 3, 6, 512, 12, "DC")

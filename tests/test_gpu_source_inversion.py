@@ -99,6 +99,30 @@ def test_short_and_odd_traces_both_kernels(gpu, n, t):
                     (metric, norm, allat, cnt, np.nanmax(np.abs(sim[:m] - ref[:m])))
 
 
+@pytest.mark.parametrize("typ", si.samplers.INVERSION_TYPES)
+def test_driver_every_inversion_type_vs_reference_golden(gpu, typ):
+    """One-process runs of the reference's driver for each of its seven inversion types
+    (tests/golden/ref_samplers.npz): same seeds -> same samples, amplitude-fraction row, posterior
+    and likelihoods."""
+    import random
+    z = np.load(os.path.join(GOLDEN, "ref_samplers.npz"))
+    seed = int(z["seed_" + typ]) + 7
+    np.random.seed(seed)
+    random.seed(seed)
+    ref_MTs = z["drv_MTs_" + typ]
+    MTs, MTp, MTp_abs = si.perform_monte_carlo_sampled_waveform_inversion(
+        z["drv_d_" + typ], z["drv_G_" + typ], num_samples=ref_MTs.shape[1], M_amplitude=0.7, inversion_type=typ,
+        comparison_metric="PCC", perform_normallised_waveform_inversion=True,
+        compare_all_waveforms_simultaneously=False, reference_stream=True)
+    assert MTs.shape == ref_MTs.shape
+    assert np.allclose(MTs, ref_MTs, rtol=0, atol=1e-13, equal_nan=True)
+    ok = np.isfinite(z["drv_MTp_absolute_" + typ])
+    assert ok.all() or typ == "single_force_crack_no_coupling"  # the arccos sampler may emit NaN (Appendix A-2)
+    assert np.allclose(MTp_abs[ok], z["drv_MTp_absolute_" + typ][ok], rtol=TOL, atol=1e-12)
+    if ok.all():
+        assert np.allclose(MTp, z["drv_MTp_" + typ], rtol=TOL, atol=1e-12)
+
+
 def test_million_samples_best_is_truth(gpu):
     """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
     rng = np.random.default_rng(0)
