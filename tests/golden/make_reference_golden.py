@@ -104,8 +104,36 @@ SAMPLERS = {"full_mt": "generate_random_MT", "DC": "generate_random_DC_MT",
             "single_force_crack_no_coupling": "generate_random_single_force_crack_uncoupled_tensor"}
 
 
+class _InProcess:
+    """Stand-in for the `multiprocessing` module inside the reference's driver: runs the worker in
+    THIS process.  Needed for the coupled types only -- Python 3 re-seeds the stdlib `random` module
+    in every forked child (os.register_at_fork), which the reference's Python 2 did not, so a forked
+    worker's amplitude fractions would not be reproducible from the seed.  The code under test
+    (driver, worker, samplers, metrics) is still the reference's."""
+
+    class Process:
+        def __init__(self, target, args):
+            self.target, self.args = target, args
+
+        def start(self):
+            self.target(*self.args)
+
+        def join(self):
+            pass
+
+    class _Manager:
+        @staticmethod
+        def dict():
+            return {}
+
+    @staticmethod
+    def Manager():
+        return _InProcess._Manager()
+
+
 def samplers_case(ref, name, nsamp=48, ndrv=40):
     out = {}
+    ref.multiprocessing = _InProcess
     for idx, (typ, fn) in enumerate(SAMPLERS.items()):
         seed = 1000 + idx
         np.random.seed(seed)
