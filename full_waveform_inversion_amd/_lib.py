@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -74,7 +74,12 @@ SIGNATURES = {
     "fwi_mc_score": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P,
                                C.POINTER(_D)]),
     "fwi_mc_forward": (C.c_int, [_I32, _I32, _I32, _I32, _I64, _P, _P, _P]),
+    "fwi_mc_invert": (C.c_int, [_I32, _I32, C.c_uint64, _I64, _I64, _D, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32,
+                                _P, _P, _P, _P, _P, C.POINTER(_D)]),
+    "fwi_mc_sample": (C.c_int, [_I32, _I32, C.c_uint64, _I64, _I64, _D, _P, _P]),
 }
+MC_INVERSION_TYPES = {"full_mt": 0, "DC": 1, "single_force": 2, "DC_single_force_couple": 3,
+                      "DC_single_force_no_coupling": 4, "DC_crack_couple": 5, "single_force_crack_no_coupling": 6}
 MC_METRICS = {"VR": 0, "CC": 1, "PCC": 2, "CC-shift": 3, "gau": 4}
 
 _lib = None

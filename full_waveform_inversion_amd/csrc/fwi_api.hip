@@ -1295,6 +1295,9 @@ int fwi_synchronize(fwi_ctx *ctx) {
 // The reference's real hot loop: batched scoring of source samples.
 // ---------------------------------------------------------------------------------------------
 namespace fwi {
+hipError_t launch_mc_sample(int type, uint64_t seed, int64_t first, int64_t nsamp, double amplitude, double *Ms,
+                            int64_t ld, double *frac, hipStream_t s);
+int mc_sampler_components(int type);
 hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,
                            int k, int n, int t, int64_t nsamp, int metric, int normalise, int all_at_once,
                            double gau_sigma, double *sim, double *like, hipStream_t s);
@@ -1339,15 +1342,21 @@ int mc_check_args(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
     return FWI_OK;
 }
 
-}  // namespace
+// Device sampler request of fwi_mc_invert (type < 0: none, the samples come from the host).
+struct McSampler {
+    int type = -1;
+    uint64_t seed = 0;
+    int64_t first = 0;
+    double amplitude = 1.0;
+    double *samples_out = nullptr, *frac_out = nullptr;
+};
 
-extern "C" {
-
-int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
-                 const double *data, const double *samples, int32_t metric, int32_t normalise,
-                 int32_t all_at_once, double *similarity_out, double *likelihood_out, double *posterior_out,
-                 double *kernel_ms_out) {
-    int rc = mc_check_args("fwi_mc_score", device, k, n, t, nsamp, green, data, samples);
+// Shared body of fwi_mc_score (host samples) and fwi_mc_invert (samples drawn on the device).
+int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
+                  const double *green, const double *data, const double *samples, const McSampler &smp,
+                  int32_t metric, int32_t normalise, int32_t all_at_once, double *similarity_out,
+                  double *likelihood_out, double *posterior_out, double *kernel_ms_out) {
+    int rc = mc_check_args(fn, device, k, n, t, nsamp, green, data, smp.type >= 0 ? (const void *)green : samples);
     if (rc) return rc;
     if (!similarity_out || metric < FWI_MC_VR || metric > FWI_MC_GAU) {
         g_create_error = "fwi_mc_score: bad metric or null output";
@@ -1409,7 +1418,15 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
     MCCHK(hipMalloc(&like.p, sb));
     MCCHK(hipMemcpy(G.p, green, gb, hipMemcpyHostToDevice));
     MCCHK(hipMemcpy(d.p, data, db, hipMemcpyHostToDevice));
-    MCCHK(hipMemcpy(M.p, samples, mb, hipMemcpyHostToDevice));
+    DevBuf fr;
+    if (smp.type >= 0) {
+        MCCHK(hipMalloc(&fr.p, sb));
+        hipError_t se = fwi::launch_mc_sample(smp.type, smp.seed, smp.first, nsamp, smp.amplitude, (double *)M.p,
+                                              nsamp, (double *)fr.p, nullptr);
+        if (se != hipSuccess) return mc_fail(FWI_EHIP, "mc_sample_kernel launch", se);
+    } else {
+        MCCHK(hipMemcpy(M.p, samples, mb, hipMemcpyHostToDevice));
+    }
     MCCHK(hipMemcpy(dm.p, dmom.data(), dmom.size() * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     MCCHK(hipEventCreate(&e0));
@@ -1426,6 +1443,8 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (kernel_ms_out) *kernel_ms_out = ms;
+    if (smp.samples_out) MCCHK(hipMemcpy(smp.samples_out, M.p, mb, hipMemcpyDeviceToHost));
+    if (smp.frac_out) MCCHK(hipMemcpy(smp.frac_out, fr.p, sb, hipMemcpyDeviceToHost));
     if (likelihood_out || posterior_out) {
         std::vector<double> tmp;
         double *L = likelihood_out;
@@ -1441,6 +1460,62 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
             for (int64_t i = 0; i < nsamp; ++i) posterior_out[i] = L[i] * p_model / p_data;
         }
     }
+    return FWI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,
+                 const double *data, const double *samples, int32_t metric, int32_t normalise,
+                 int32_t all_at_once, double *similarity_out, double *likelihood_out, double *posterior_out,
+                 double *kernel_ms_out) {
+    return mc_score_impl("fwi_mc_score", device, k, n, t, nsamp, green, data, samples, McSampler(), metric,
+                         normalise, all_at_once, similarity_out, likelihood_out, posterior_out, kernel_ms_out);
+}
+
+int fwi_mc_invert(int32_t device, int32_t inversion_type, uint64_t seed, int64_t first_sample, int64_t nsamp,
+                  double amplitude, int32_t k, int32_t n, int32_t t, const double *green, const double *data,
+                  int32_t metric, int32_t normalise, int32_t all_at_once, double *samples_out, double *frac_out,
+                  double *similarity_out, double *likelihood_out, double *posterior_out, double *kernel_ms_out) {
+    const int nc = fwi::mc_sampler_components(inversion_type);
+    if (nc == 0 || nc != n || first_sample < 0) {
+        g_create_error = nc == 0 ? "fwi_mc_invert: unknown inversion_type"
+                                 : nc != n ? "fwi_mc_invert: the Green's functions must have the inversion type's "
+                                             "number of components (6, 3 or 9)"
+                                           : "fwi_mc_invert: negative first_sample";
+        return FWI_EINVAL;
+    }
+    McSampler smp;
+    smp.type = inversion_type;
+    smp.seed = seed;
+    smp.first = first_sample;
+    smp.amplitude = amplitude;
+    smp.samples_out = samples_out;
+    smp.frac_out = frac_out;
+    return mc_score_impl("fwi_mc_invert", device, k, n, t, nsamp, green, data, nullptr, smp, metric, normalise,
+                         all_at_once, similarity_out, likelihood_out, posterior_out, kernel_ms_out);
+}
+
+int fwi_mc_sample(int32_t device, int32_t inversion_type, uint64_t seed, int64_t first_sample, int64_t nsamp,
+                  double amplitude, double *samples_out, double *frac_out) {
+    const int n = fwi::mc_sampler_components(inversion_type);
+    if (n == 0 || nsamp < 1 || first_sample < 0 || !samples_out) {
+        g_create_error = "fwi_mc_sample: unknown inversion_type, nsamp < 1, negative first_sample or null output";
+        return FWI_EINVAL;
+    }
+    int rc = mc_check_args("fwi_mc_sample", device, 1, n, 1, nsamp, samples_out, samples_out, samples_out);
+    if (rc) return rc;
+    MCCHK(hipSetDevice(device));
+    DevBuf M, fr;
+    MCCHK(hipMalloc(&M.p, (size_t)n * nsamp * 8));
+    MCCHK(hipMalloc(&fr.p, (size_t)nsamp * 8));
+    hipError_t se = fwi::launch_mc_sample(inversion_type, seed, first_sample, nsamp, amplitude, (double *)M.p, nsamp,
+                                          (double *)fr.p, nullptr);
+    if (se != hipSuccess) return mc_fail(FWI_EHIP, "mc_sample_kernel launch", se);
+    MCCHK(hipMemcpy(samples_out, M.p, (size_t)n * nsamp * 8, hipMemcpyDeviceToHost));
+    if (frac_out) MCCHK(hipMemcpy(frac_out, fr.p, (size_t)nsamp * 8, hipMemcpyDeviceToHost));
     return FWI_OK;
 }
 

@@ -466,6 +466,239 @@ __global__ void mc_forward_kernel(const double *__restrict__ G, const double *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side source samplers: the reference's seven generate_random_* functions
+// (full_waveform_inversion.py:282-510), one thread per sample.  The deterministic maps are the
+// reference's (same steps as full_waveform_inversion_amd/samplers.py, which is pinned to reference
+// golden vectors); the deviates come from a counter-based generator so that sample i is a pure
+// function of (seed, i) whatever the launch shape or the number of GPUs:
+//   Philox4x32-10, counter (i_lo, i_hi, block, 0), key (seed_lo, seed_hi); one block = 4 x u32 =
+//   two doubles in [0, 1) (53 bits each, (a >> 5) * 2^26 + (b >> 6), as numpy forms them);
+//   blocks 0..2  -> normal pairs (z0, z1), (z2, z3), (z4, z5) by Box-Muller
+//                   r = sqrt(-2 ln(1 - u_a)), z = r cos / sin(2 pi u_b);
+//   blocks 8, 9  -> uniforms (U0, U1), (U2, U3): u_theta = 2 U0 - 1, r_phi = U1,
+//                   r_quadrant = U2, frac = U3 (the coupled non-crack types take frac = U0).
+// oracle/mc_oracle.py restates the generator (known-answer vectors of Philox4x32-10 included).
+// ---------------------------------------------------------------------------------------------
+enum { MC_T_FULL = 0, MC_T_DC = 1, MC_T_SF = 2, MC_T_DC_SF_C = 3, MC_T_DC_SF_U = 4, MC_T_DC_CRACK = 5,
+       MC_T_SF_CRACK = 6 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct McRng {
+    uint32_t i_lo, i_hi, k0, k1;
+    __device__ void uniforms(uint32_t block, double &ua, double &ub) const {
+        uint32_t r[4];
+        philox4x32_10(i_lo, i_hi, block, 0u, k0, k1, r);
+        ua = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+        ub = ((double)(r[2] >> 5) * 67108864.0 + (double)(r[3] >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    __device__ void normals(uint32_t block, double &z0, double &z1) const {
+        double ua, ub;
+        uniforms(block, ua, ub);
+        const double r = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925 * ub;
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        z0 = r * cs;
+        z1 = r * sn;
+    }
+};
+
+// the reference's two-step normalisation (:288-290): a / (sum a^2)^-0.5, then / norm of that
+template <int N>
+__device__ __forceinline__ void mc_unit(double (&a)[N]) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) s += a[j] * a[j];
+    const double f = pow(s, -0.5);
+    double s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        a[j] = a[j] / f;
+        s1 += a[j] * a[j];
+    }
+    const double nrm = sqrt(s1);
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[j] = a[j] / nrm;
+}
+
+// rot_mt_by_theta_phi (:226-232): R_phi (R_theta M R_theta^T) R_phi^T, then the six-vector (:206-208)
+__device__ void mc_rot_six(const double (&Min)[3][3], double theta, double phi, double (&six)[6]) {
+    double st, ct, sp, cp;
+    sincos(theta, &st, &ct);
+    sincos(phi, &sp, &cp);
+    const double Rt[3][3] = {{ct, 0.0, st}, {0.0, 1.0, 0.0}, {-st, 0.0, ct}};
+    const double Rp[3][3] = {{cp, -sp, 0.0}, {sp, cp, 0.0}, {0.0, 0.0, 1.0}};
+    double A[3][3], B[3][3];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const double(&R)[3][3] = pass ? Rp : Rt;
+        const double(&S)[3][3] = pass ? B : Min;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // A = S R^T
+#pragma unroll
+            for (int j = 0; j < 3; ++j) A[i][j] = S[i][0] * R[j][0] + S[i][1] * R[j][1] + S[i][2] * R[j][2];
+        double C[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)  // C = R A
+#pragma unroll
+            for (int j = 0; j < 3; ++j) C[i][j] = R[i][0] * A[0][j] + R[i][1] * A[1][j] + R[i][2] * A[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) B[i][j] = C[i][j];
+    }
+    const double r2 = 1.4142135623730951;
+    six[0] = B[0][0]; six[1] = B[1][1]; six[2] = B[2][2];
+    six[3] = r2 * B[0][1]; six[4] = r2 * B[0][2]; six[5] = r2 * B[1][2];
+}
+
+__device__ __forceinline__ void mc_norm6(double (&six)[6]) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += six[j] * six[j];
+    const double nrm = sqrt(s);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) six[j] = six[j] / nrm;
+}
+
+// crack tensor on the lune boundary (:393-424): diagonal (c - sqrt2 s, same, c + 2 sqrt2 s) * scale
+__device__ void mc_crack(double u_theta, double r_phi, double r_quadrant, double (&M)[3][3]) {
+    const double pi = 3.141592653589793;
+    const double theta_l = u_theta * pi / 2.0, phi_l = r_phi <= 0.5 ? 0.0 : pi / 3;
+    double ang = atan(sin(phi_l) / sin(theta_l));
+    if (r_quadrant > 0.25 && r_quadrant <= 0.5) ang += pi;
+    if (r_quadrant > 0.5 && r_quadrant <= 0.75) ang += pi / 2;
+    if (r_quadrant > 0.75 && r_quadrant <= 1.0) ang += 3 * pi / 2;
+    double s, c;
+    sincos(ang, &s, &c);
+    const double scale = pow(4.0 * (s * s) + c * c, -0.5) / sqrt(3.0);
+    const double r2 = 1.4142135623730951;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i][j] = 0.0;
+    M[0][0] = M[1][1] = scale * (c - r2 * s);
+    M[2][2] = scale * (c + 2.0 * r2 * s);
+}
+
+__global__ __launch_bounds__(256) void mc_sample_kernel(int type, uint64_t seed, int64_t first, int64_t nsamp,
+                                                        double amplitude, double *__restrict__ Ms, int64_t ld,
+                                                        double *__restrict__ frac_out) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nsamp) return;
+    const uint64_t idx = (uint64_t)(first + s);
+    const McRng rng = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)seed, (uint32_t)(seed >> 32)};
+    double z[6];
+    rng.normals(0, z[0], z[1]);
+    rng.normals(1, z[2], z[3]);
+    double out[9];
+    double frac = 0.0;
+    int n = 6;
+    if (type == MC_T_FULL) {
+        rng.normals(2, z[4], z[5]);
+        mc_unit<6>(z);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[j] = z[j];
+    } else if (type == MC_T_SF) {
+        double a[3] = {z[0], z[1], z[2]};
+        mc_unit<3>(a);
+        n = 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[j] = a[j];
+    } else {
+        rng.normals(2, z[4], z[5]);
+        double U0, U1, U2, U3;
+        rng.uniforms(8, U0, U1);
+        rng.uniforms(9, U2, U3);
+        const bool crack = type == MC_T_DC_CRACK || type == MC_T_SF_CRACK;
+        frac = crack ? U3 : U0;
+        // orientation vector: z[0..2], except the single-force-crack type, whose first triple is the force
+        double a[3];
+        const int o = type == MC_T_SF_CRACK ? 3 : 0;
+        a[0] = z[o]; a[1] = z[o + 1]; a[2] = z[o + 2];
+        mc_unit<3>(a);
+        double theta, phi;
+        if (type == MC_T_SF_CRACK) {  // :497-498
+            theta = acos(a[2]);
+            phi = acos(a[0] / sin(theta));
+        } else {  // :308-309
+            theta = atan2(sqrt(a[0] * a[0] + a[1] * a[1]), a[2]);
+            phi = atan2(a[1], a[0]);
+        }
+        double Mt[3][3] = {{0.0, 0.0, 1.0}, {0.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};  // the double couple (:299)
+        if (crack) {
+            double Cr[3][3];
+            mc_crack(2.0 * U0 - 1.0, U1, U2, Cr);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Mt[i][j] = type == MC_T_DC_CRACK ? frac * Mt[i][j] + (1.0 - frac) * Cr[i][j] : Cr[i][j];
+        }
+        double six[6];
+        mc_rot_six(Mt, theta, phi, six);
+        if (type != MC_T_SF_CRACK) mc_norm6(six);  // the single-force-crack tensor is not re-normalised (:500-503)
+        if (type == MC_T_DC || type == MC_T_DC_CRACK) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out[j] = six[j];
+        } else {
+            n = 9;
+            double f[3];
+            if (type == MC_T_DC_SF_C) {  // force along the slip vector: rotate (1, 0, 0), NED -> END (:356-358)
+                double st, ct, sp, cp;
+                sincos(theta, &st, &ct);
+                sincos(phi, &sp, &cp);
+                const double v0 = ct, v2 = -st;              // R_theta (1, 0, 0)
+                const double w0 = cp * v0, w1 = sp * v0;     // R_phi v
+                f[0] = w1; f[1] = w0; f[2] = v2;
+            } else {
+                const int fo = type == MC_T_SF_CRACK ? 0 : 3;
+                f[0] = z[fo]; f[1] = z[fo + 1]; f[2] = z[fo + 2];
+                mc_unit<3>(f);
+            }
+            // amplitude split: DC part * frac, force * (1 - frac) (:362-363, :378-379); the
+            // single-force-crack type gives frac to the FORCE (:507-509)
+            const double wt = type == MC_T_SF_CRACK ? 1.0 - frac : frac, wf = 1.0 - wt;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) out[j] = six[j] * wt;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[6 + j] = f[j] * wf;
+        }
+    }
+    for (int j = 0; j < n; ++j) Ms[(int64_t)j * ld + s] = out[j] * amplitude;
+    if (frac_out) frac_out[s] = frac;
+}
+
+int mc_sampler_components(int type) {
+    switch (type) {
+        case MC_T_FULL: case MC_T_DC: case MC_T_DC_CRACK: return 6;
+        case MC_T_SF: return 3;
+        case MC_T_DC_SF_C: case MC_T_DC_SF_U: case MC_T_SF_CRACK: return 9;
+        default: return 0;
+    }
+}
+
+hipError_t launch_mc_sample(int type, uint64_t seed, int64_t first, int64_t nsamp, double amplitude, double *Ms,
+                            int64_t ld, double *frac, hipStream_t s) {
+    const unsigned blocks = (unsigned)((nsamp + 255) / 256);
+    hipLaunchKernelGGL(mc_sample_kernel, dim3(blocks), dim3(256), 0, s, type, seed, first, nsamp, amplitude, Ms, ld,
+                       frac);
+    return hipGetLastError();
+}
+
 // Gt = G and d packed [k][t][n + 1] (row = g_0..g_{n-1}, d) followed by >= 1 KiB of zeros; given for
 // n = 3 / 6 / 9, which take the lane-per-sample kernel
 hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,

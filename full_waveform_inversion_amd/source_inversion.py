@@ -78,6 +78,51 @@ def compare_synth_to_real_waveforms(real_data_array, green_func_array, M, compar
                                device)[0][0])
 
 
+def sample_on_device(inversion_type, num_samples, seed=0, first_sample=0, M_amplitude=1.0, device=0):
+    """``num_samples`` sources of ``inversion_type`` drawn by the device sampler (``fwi_mc_sample``):
+    the reference's generate_random_* maps (:282-510) applied to counter-based deviates, sample
+    ``i`` a pure function of ``(seed, first_sample + i)``.  Returns ``(MTs (n, N), amp_frac (N,))``."""
+    if inversion_type not in _lib.MC_INVERSION_TYPES:
+        raise ValueError("inversion_type must be one of %s" % sorted(_lib.MC_INVERSION_TYPES))
+    n = samplers.NUM_COMPONENTS[inversion_type]
+    M, frac = np.empty((n, int(num_samples))), np.empty(int(num_samples))
+    _lib.check(None, _lib.load().fwi_mc_sample(device, _lib.MC_INVERSION_TYPES[inversion_type], int(seed),
+                                               int(first_sample), int(num_samples), float(M_amplitude),
+                                               _p(M), _p(frac)))
+    return M, frac
+
+
+def invert_on_device(real_data_array, green_func_array, num_samples, inversion_type="full_mt", seed=0,
+                     first_sample=0, M_amplitude=1.0, comparison_metric="VR",
+                     perform_normallised_waveform_inversion=True, compare_all_waveforms_simultaneously=True,
+                     return_samples=True, device=0, return_timing=False):
+    """Steps 3-7 of the reference's worker (:713-774) entirely on the GPU (``fwi_mc_invert``): draw,
+    forward-model, compare, likelihood.  Returns ``(MTs or None, amp_frac or None, similarity,
+    likelihood, posterior)`` [+ kernel ms]; with ``return_samples=False`` no sample crosses PCIe
+    (any of them can be regenerated later from ``(seed, index)`` with ``sample_on_device``)."""
+    G, d = _f64(green_func_array), _f64(real_data_array)
+    if G.ndim != 3 or d.shape != (G.shape[0], G.shape[2]):
+        raise ValueError("shapes must be G (k, n, t), data (k, t)")
+    if inversion_type not in _lib.MC_INVERSION_TYPES:
+        raise ValueError("inversion_type must be one of %s" % sorted(_lib.MC_INVERSION_TYPES))
+    if comparison_metric not in _lib.MC_METRICS:
+        raise ValueError("comparison_metric must be one of %s" % sorted(_lib.MC_METRICS))
+    k, n, t = G.shape
+    N = int(num_samples)
+    M = np.empty((n, N)) if return_samples else None
+    frac = np.empty(N) if return_samples else None
+    sim, like, post = np.empty(N), np.empty(N), np.empty(N)
+    ms = C.c_double(0.0)
+    _lib.check(None, _lib.load().fwi_mc_invert(
+        device, _lib.MC_INVERSION_TYPES[inversion_type], int(seed), int(first_sample), N, float(M_amplitude),
+        k, n, t, _p(G), _p(d), _lib.MC_METRICS[comparison_metric],
+        int(bool(perform_normallised_waveform_inversion)), int(bool(compare_all_waveforms_simultaneously)),
+        _p(M) if return_samples else None, _p(frac) if return_samples else None, _p(sim), _p(like), _p(post),
+        C.byref(ms)))
+    out = (M, frac, sim, like, post)
+    return out + (ms.value,) if return_timing else out
+
+
 def random_full_mt(num_samples, rng):
     """Unit 6-vectors uniform on the 5-sphere (generate_random_MT, :282-293)."""
     return samplers.draw("full_mt", num_samples, rng)[0]
@@ -94,22 +139,34 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
                                                    perform_normallised_waveform_inversion=True,
                                                    compare_all_waveforms_simultaneously=True, MTs=None,
                                                    seed=0, device=0, reference_stream=False,
-                                                   return_absolute_similarity_values_switch=True):
+                                                   return_absolute_similarity_values_switch=True,
+                                                   sampler="device"):
     """The reference's driver (:786-870) with the sample loop on the GPU.
 
     ``inversion_type`` is any of the reference's seven (:740-760): ``full_mt``, ``DC``,
     ``single_force``, ``DC_single_force_couple``, ``DC_single_force_no_coupling``,
-    ``DC_crack_couple``, ``single_force_crack_no_coupling``; samples are drawn by ``samplers.draw``
-    from ``default_rng(seed)``, or -- ``reference_stream=True`` -- from the global ``numpy.random`` /
-    ``random`` generators in the reference's order, which reproduces a one-process run of the
-    reference seeded the same way.  ``MTs (n, N)`` may be supplied instead.
+    ``DC_crack_couple``, ``single_force_crack_no_coupling``.  Samples are drawn on the GPU (``sampler="device"``:
+    ``fwi_mc_invert``, counter-based deviates keyed by ``seed``), on the host by ``samplers.draw``
+    from ``default_rng(seed)`` (``sampler="host"``), or -- ``reference_stream=True`` -- on the host
+    from the global ``numpy.random`` / ``random`` generators in the reference's order, which
+    reproduces a one-process run of the reference seeded the same way.  ``MTs (n, N)`` may be
+    supplied instead.
 
     Returns ``(MTs, MTp, MTp_absolute)`` like the reference: the samples (scaled by ``M_amplitude``,
     with the sampler's amplitude fraction appended as an extra row for the four coupled types,
     :852-853), the posterior ``L / sum L`` (:847-848) and the likelihoods ``exp(-(1-s)/2)`` (:774;
     ``[]`` when ``return_absolute_similarity_values_switch`` is false, :866-869).
     """
+    if sampler not in ("device", "host"):
+        raise ValueError("sampler must be 'device' or 'host'")
     frac = None
+    if MTs is None and sampler == "device" and not reference_stream:
+        MTs, frac, _, like, post = invert_on_device(
+            real_data_array, green_func_array, num_samples, inversion_type, seed, 0, M_amplitude, comparison_metric,
+            perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously, True, device)
+        if inversion_type in samplers.COUPLED_TYPES:
+            MTs = np.vstack((MTs, frac))
+        return MTs, post, (like if return_absolute_similarity_values_switch else [])
     if MTs is None:
         rng = None if reference_stream else np.random.default_rng(seed)
         MTs, frac = samplers.draw(inversion_type, num_samples, rng, reference_stream)

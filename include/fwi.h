@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 5
+#define FWI_ABI_VERSION 6
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -168,7 +168,7 @@ int fwi_device_count(int32_t *n_out);
  * given samples: forward_model (:253-264), compare_synth_to_real_waveforms
  * (:584-684) with one of the five similarity metrics (:512-582), the likelihood
  * map exp(-(1-s)/2) (:774) and the posterior normalisation (:847-848).  fp64 like
- * the reference; the random samplers (:282-510) stay with the caller.
+ * the reference; the samples are the caller's (fwi_mc_invert draws them on the device).
  *   green   (k, n, t)   Green's functions        data (k, t)   observed traces
  *   samples (n, nsamp)  source vectors, the reference's MTs[:, i] layout
  * Stateless: buffers are uploaded, scored and freed inside the call.
@@ -180,6 +180,35 @@ int fwi_mc_score(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp,
                  int32_t all_at_once, double *similarity_out /* nsamp */,
                  double *likelihood_out /* nsamp or NULL */, double *posterior_out /* nsamp or NULL */,
                  double *kernel_ms_out /* or NULL */);
+
+/* The whole loop body of PARALLEL_worker_mc_inv (:713-774) on the device, samplers included:
+ * sample i = first_sample .. first_sample + nsamp - 1 of `inversion_type` is drawn by the
+ * reference's generate_random_* map (:282-510) from counter-based deviates (Philox4x32-10 keyed by
+ * `seed`, counter = sample index; a pure function of (seed, i), so ranks / calls can split a
+ * run by index ranges), scaled by `amplitude` (M_amplitude, :741-760) and scored like
+ * fwi_mc_score.  n must be the type's component count (6, 3 or 9).  samples_out (n, nsamp) and
+ * frac_out (nsamp; the sampler's amplitude fraction, 0 for the uncoupled types) may be NULL when
+ * only the scores are wanted -- then no sample ever crosses PCIe. */
+enum {
+    FWI_MC_FULL_MT = 0,                        /* generate_random_MT                              :282 */
+    FWI_MC_DC = 1,                             /* generate_random_DC_MT                           :295 */
+    FWI_MC_SINGLE_FORCE = 2,                   /* generate_random_single_force_vector             :320 */
+    FWI_MC_DC_SINGLE_FORCE_COUPLE = 3,         /* generate_random_DC_single_force_coupled_tensor  :333 */
+    FWI_MC_DC_SINGLE_FORCE_NO_COUPLING = 4,    /* generate_random_DC_single_force_uncoupled_tensor :369 */
+    FWI_MC_DC_CRACK_COUPLE = 5,                /* generate_random_DC_crack_coupled_tensor         :384 */
+    FWI_MC_SINGLE_FORCE_CRACK_NO_COUPLING = 6  /* generate_random_single_force_crack_uncoupled_tensor :448 */
+};
+
+int fwi_mc_invert(int32_t device, int32_t inversion_type, uint64_t seed, int64_t first_sample, int64_t nsamp,
+                  double amplitude, int32_t k, int32_t n, int32_t t, const double *green, const double *data,
+                  int32_t metric, int32_t normalise, int32_t all_at_once,
+                  double *samples_out /* (n, nsamp) or NULL */, double *frac_out /* nsamp or NULL */,
+                  double *similarity_out /* nsamp */, double *likelihood_out /* nsamp or NULL */,
+                  double *posterior_out /* nsamp or NULL */, double *kernel_ms_out /* or NULL */);
+
+/* The device sampler alone: samples_out (n, nsamp), frac_out (nsamp) or NULL. */
+int fwi_mc_sample(int32_t device, int32_t inversion_type, uint64_t seed, int64_t first_sample, int64_t nsamp,
+                  double amplitude, double *samples_out, double *frac_out);
 
 /* forward_model for a batch: synth_out (nsamp, k, t).  [full_waveform_inversion.py:253-264] */
 int fwi_mc_forward(int32_t device, int32_t k, int32_t n, int32_t t, int64_t nsamp, const double *green,

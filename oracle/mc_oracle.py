@@ -97,3 +97,76 @@ def score_samples(G, d, Ms, metric="VR", normalise=False, all_at_once=False):
     sims = np.array([compare_synth_to_real_waveforms(d, forward_model(G, Ms[:, i]), metric, normalise,
                                                      all_at_once) for i in range(Ms.shape[1])], float)
     return sims, likelihood(sims)
+
+
+# ---------------------------------------------------------------------------------------------
+# The device sampler's deviate generator (csrc/mc_kernels.hip, mc_sample_kernel).  BUILD-DEFINED:
+# the reference draws from numpy's / the stdlib's global Mersenne Twisters, whose sequential
+# streams cannot be split over GPU threads; the device uses a counter-based generator instead.
+# Philox4x32-10 is the published algorithm of Salmon et al., "Parallel random numbers: as easy as
+# 1, 2, 3" (SC'11); PHILOX_KAT are two known-answer vectors from its Random123 distribution
+# (kat_vectors: the all-zero input and the digits-of-pi input), checked in tests/test_mc_oracle.py.  The deterministic maps from deviates to
+# samples are the reference's and are pinned separately (tests/test_samplers.py).
+# ---------------------------------------------------------------------------------------------
+PHILOX_KAT = [  # (counter[4], key[2]) -> output[4]
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32 with 10 rounds on uint32 arrays (broadcast together); returns 4 uint32 arrays."""
+    u64 = np.uint64
+    c0, c1, c2, c3 = [np.asarray(c, dtype=u64) & u64(0xFFFFFFFF) for c in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = u64(int(k0) & 0xFFFFFFFF), u64(int(k1) & 0xFFFFFFFF)
+    mask, sh = u64(0xFFFFFFFF), u64(32)
+    for _ in range(10):
+        p0, p1 = u64(0xD2511F53) * c0, u64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> sh) ^ c1 ^ k0, p1 & mask, (p0 >> sh) ^ c3 ^ k1, p0 & mask
+        k0, k1 = (k0 + u64(0x9E3779B9)) & mask, (k1 + u64(0xBB67AE85)) & mask
+    return c0, c1, c2, c3
+
+
+def _device_uniform_pair(idx, seed, block):
+    """Two doubles in [0, 1) of sample indices ``idx`` from Philox block ``block``."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    r = philox4x32_10(idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32), np.uint64(block), np.uint64(0),
+                      int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    r = [x.astype(np.float64) for x in (r[0] >> np.uint64(5), r[1] >> np.uint64(6), r[2] >> np.uint64(5),
+                                        r[3] >> np.uint64(6))]
+    scale = 1.0 / 9007199254740992.0
+    return (r[0] * 67108864.0 + r[1]) * scale, (r[2] * 67108864.0 + r[3]) * scale
+
+
+def _device_normal_pair(idx, seed, block):
+    ua, ub = _device_uniform_pair(idx, seed, block)
+    r, ang = np.sqrt(-2.0 * np.log(1.0 - ua)), 6.283185307179586476925 * ub
+    return r * np.cos(ang), r * np.sin(ang)
+
+
+def device_sampler_deviates(inversion_type, seed, first_sample, num_samples):
+    """The deviates mc_sample_kernel feeds the reference's sampler maps, keyed like
+    ``full_waveform_inversion_amd.samplers.draw_deviates``: blocks 0..2 are normal pairs
+    (z0..z5), blocks 8 and 9 the uniforms (U0, U1), (U2, U3)."""
+    idx = np.arange(first_sample, first_sample + num_samples, dtype=np.uint64)
+    z = np.stack([v for b in range(3) for v in _device_normal_pair(idx, seed, b)], axis=1)  # (N, 6)
+    U0, U1 = _device_uniform_pair(idx, seed, 8)
+    U2, U3 = _device_uniform_pair(idx, seed, 9)
+    if inversion_type == "full_mt":
+        return {"z6": z}
+    if inversion_type in ("DC", "single_force"):
+        return {"z3": z[:, :3]}
+    if inversion_type == "DC_single_force_couple":
+        return {"z3": z[:, :3], "frac": U0}
+    if inversion_type == "DC_single_force_no_coupling":
+        return {"z3_dc": z[:, :3], "z3_sf": z[:, 3:], "frac": U0}
+    crack = {"u_theta": 2.0 * U0 - 1.0, "r_phi": U1, "r_quadrant": U2, "frac": U3}
+    if inversion_type == "DC_crack_couple":
+        crack["z3"] = z[:, :3]
+        return crack
+    if inversion_type == "single_force_crack_no_coupling":
+        crack["z3_sf"], crack["z3_rot"] = z[:, :3], z[:, 3:]
+        return crack
+    raise ValueError(inversion_type)

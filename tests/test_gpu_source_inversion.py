@@ -123,6 +123,50 @@ def test_driver_every_inversion_type_vs_reference_golden(gpu, typ):
         assert np.allclose(MTp, z["drv_MTp_" + typ], rtol=TOL, atol=1e-12)
 
 
+@pytest.mark.parametrize("typ", si.samplers.INVERSION_TYPES)
+def test_device_sampler_vs_oracle_deviates_and_reference_maps(gpu, typ):
+    """mc_sample_kernel == the reference's sampler map (samplers.py, pinned to reference goldens) applied to
+    the oracle's restatement of the device generator (Philox4x32-10 + Box-Muller, KAT-checked)."""
+    seed, first, N, amp = 0x1234567890ABCDEF, (1 << 32) - 100, 777, 1.7   # index range crossing 2^32
+    M, frac = si.sample_on_device(typ, N, seed, first, amp)
+    with np.errstate(all="ignore"):
+        ref_M, ref_frac = si.samplers.from_deviates(typ, mo.device_sampler_deviates(typ, seed, first, N))
+    assert M.shape == ref_M.shape
+    bad = ~np.isfinite(ref_M).all(axis=0)  # arccos quirk of the single-force-crack sampler (Appendix A-2)
+    assert bad.mean() < 0.01 and np.array_equal(bad, ~np.isfinite(M).all(axis=0))
+    assert np.allclose(M[:, ~bad], amp * ref_M[:, ~bad], rtol=0, atol=2e-11), np.abs(M - amp * ref_M)[:, ~bad].max()
+    if ref_frac is not None:
+        assert np.allclose(frac, ref_frac, rtol=0, atol=1e-15)
+    # a sub-range regenerates the same samples
+    M2, _ = si.sample_on_device(typ, 50, seed, first + 300, amp)
+    assert np.array_equal(M2, M[:, 300:350], equal_nan=True)
+
+
+@pytest.mark.parametrize("typ", ["full_mt", "DC_single_force_couple", "DC_crack_couple"])
+def test_invert_on_device_equals_sample_then_score(gpu, typ):
+    rng = np.random.default_rng(8)
+    n, k, t, N = si.samplers.NUM_COMPONENTS[typ], 5, 96, 1000
+    G = rng.standard_normal((k, n, t))
+    d = np.einsum("kjt,j->kt", G, rng.standard_normal(n))
+    M, frac, sim, like, post = si.invert_on_device(d, G, N, typ, seed=5, M_amplitude=0.5, comparison_metric="CC",
+                                                   perform_normallised_waveform_inversion=True,
+                                                   compare_all_waveforms_simultaneously=False)
+    M2, frac2 = si.sample_on_device(typ, N, 5, 0, 0.5)
+    assert np.array_equal(M, M2) and np.array_equal(frac, frac2)
+    sim2, like2, post2 = si.score_samples(d, G, M, "CC", True, False)
+    assert np.array_equal(sim, sim2) and np.array_equal(like, like2) and np.array_equal(post, post2)
+    none = si.invert_on_device(d, G, N, typ, seed=5, M_amplitude=0.5, comparison_metric="CC",
+                               perform_normallised_waveform_inversion=True,
+                               compare_all_waveforms_simultaneously=False, return_samples=False)
+    assert none[0] is None and none[1] is None and np.array_equal(none[2], sim)
+    MTs, MTp, MTp_abs = si.perform_monte_carlo_sampled_waveform_inversion(
+        d, G, N, 0.5, typ, "CC", True, False, seed=5)
+    assert MTs.shape == (n + (typ in si.samplers.COUPLED_TYPES), N) and np.array_equal(MTs[:n], M)
+    assert np.array_equal(MTp, post) and np.array_equal(MTp_abs, like)
+    with pytest.raises(FwiError):  # component count must match the type
+        si.invert_on_device(d, G[:, :2], N, typ)
+
+
 def test_million_samples_best_is_truth(gpu):
     """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
     rng = np.random.default_rng(0)

@@ -46,3 +46,25 @@ def test_driver_likelihood_and_posterior(name):
     assert np.allclose(like, z["drv_MTp_absolute"], rtol=1e-12)
     assert np.allclose(mo.posterior(like), z["drv_MTp"], rtol=1e-12)
     assert abs(mo.posterior(like).sum() - 1.0) < 1e-12
+
+
+def test_philox_known_answer_vectors():
+    """Philox4x32-10 (the device sampler's generator) against Random123's published vectors."""
+    for ctr, key, want in mo.PHILOX_KAT:
+        got = mo.philox4x32_10(*[np.array([c]) for c in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_device_deviates_are_counter_based_and_well_distributed():
+    a = mo.device_sampler_deviates("single_force_crack_no_coupling", 11, 0, 4096)
+    b = mo.device_sampler_deviates("single_force_crack_no_coupling", 11, 1000, 100)
+    for key in a:  # any index range reproduces the same per-sample deviates
+        assert np.array_equal(a[key][1000:1100], b[key])
+    z = mo.device_sampler_deviates("full_mt", 3, 0, 200000)["z6"]
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs((z ** 4).mean() - 3.0) < 0.1
+    assert np.abs(np.corrcoef(z.T) - np.eye(6)).max() < 0.01
+    c = mo.device_sampler_deviates("DC_crack_couple", 3, 0, 200000)
+    for key, lo in (("u_theta", -1.0), ("r_phi", 0.0), ("r_quadrant", 0.0), ("frac", 0.0)):
+        assert lo <= c[key].min() and c[key].max() < 1.0 and abs(c[key].mean() - (lo + 1.0) / 2) < 0.01
+    assert not np.array_equal(mo.device_sampler_deviates("DC", 1, 0, 8)["z3"],
+                              mo.device_sampler_deviates("DC", 2, 0, 8)["z3"])
