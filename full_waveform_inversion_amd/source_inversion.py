@@ -178,3 +178,36 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
     if frac is not None:
         MTs = np.vstack((MTs, frac))
     return MTs, post, (like if return_absolute_similarity_values_switch else [])
+
+
+def partition_samples(num_samples, rank, world):
+    """``(first, count)`` of ``rank``'s contiguous block of sample indices.  The reference gives
+    every worker ``int(N / P)`` samples and leaves the last ``N mod P`` slots empty (:822, SURVEY
+    Appendix A-7); here the remainder is spread over the first ranks so all ``N`` are drawn."""
+    base, extra = divmod(int(num_samples), int(world))
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
+def perform_monte_carlo_sampled_waveform_inversion_sharded(real_data_array, green_func_array, num_samples,
+                                                           rank, world, sum_over_ranks, M_amplitude=1.0,
+                                                           inversion_type="full_mt", comparison_metric="CC",
+                                                           perform_normallised_waveform_inversion=True,
+                                                           compare_all_waveforms_simultaneously=True, seed=0,
+                                                           device=0, return_samples=True):
+    """The reference's multi-process driver (:816-848) as one process per GPU: rank ``r`` draws and
+    scores the samples of its index block (the device sampler is counter-based, so the ``world``
+    blocks together are exactly the samples a single GPU would draw from ``seed``), and the only
+    exchange is the posterior's normaliser ``sum L`` -- ``sum_over_ranks(float) -> float``, one
+    scalar all-reduce (``dist.all_reduce`` or ``Engine.comm_allreduce_f64``).
+
+    Returns ``(first_index, MTs_local, MTp_local, MTp_absolute_local)``; ``MTp`` is normalised over
+    ALL ranks' samples (:847-848 with ``p_model = 1 / N``).
+    """
+    first, count = partition_samples(num_samples, rank, world)
+    M, frac, _, like, _ = invert_on_device(
+        real_data_array, green_func_array, count, inversion_type, seed, first, M_amplitude, comparison_metric,
+        perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously, return_samples, device)
+    total = float(sum_over_ranks(float(np.sum(like))))
+    if return_samples and inversion_type in samplers.COUPLED_TYPES:
+        M = np.vstack((M, frac))
+    return first, M, like / total, like

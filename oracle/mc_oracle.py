@@ -105,8 +105,9 @@ def score_samples(G, d, Ms, metric="VR", normalise=False, all_at_once=False):
 # streams cannot be split over GPU threads; the device uses a counter-based generator instead.
 # Philox4x32-10 is the published algorithm of Salmon et al., "Parallel random numbers: as easy as
 # 1, 2, 3" (SC'11); PHILOX_KAT are two known-answer vectors from its Random123 distribution
-# (kat_vectors: the all-zero input and the digits-of-pi input), checked in tests/test_mc_oracle.py.  The deterministic maps from deviates to
-# samples are the reference's and are pinned separately (tests/test_samplers.py).
+# (kat_vectors: the all-zero input and the digits-of-pi input), checked in tests/test_mc_oracle.py.
+# The deterministic maps from deviates to samples are the reference's and are pinned separately
+# (tests/test_samplers.py).
 # ---------------------------------------------------------------------------------------------
 PHILOX_KAT = [  # (counter[4], key[2]) -> output[4]
     ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),

@@ -167,6 +167,21 @@ def test_invert_on_device_equals_sample_then_score(gpu, typ):
         si.invert_on_device(d, G[:, :2], N, typ)
 
 
+def test_two_ranks_share_one_run(gpu, tmp_path):
+    """Two processes on this GPU (sample-index blocks + one scalar all-reduce over gloo) reproduce the
+    single-process device run bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _mc_dist_worker as w
+    from test_host_logic import _run_mc_world2
+    res = _run_mc_world2(tmp_path, "gpu")
+    d, G, N, typ = w.problem()
+    M, frac, sim, like, post = si.invert_on_device(d, G, N, typ, 9, 0, 1.5, "VR", False, False)
+    assert np.array_equal(np.hstack([r["M"] for r in res]), np.vstack((M, frac)))
+    assert np.array_equal(np.concatenate([r["like"] for r in res]), like)
+    assert np.allclose(np.concatenate([r["post"] for r in res]), post, rtol=1e-12, atol=0)
+
+
 def test_million_samples_best_is_truth(gpu):
     """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
     rng = np.random.default_rng(0)

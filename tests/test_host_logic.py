@@ -78,6 +78,43 @@ def test_shot_parallel_gloo_world2_matches_serial(tmp_path):
         assert np.linalg.norm(r["g"] - g) <= 1e-12 * np.linalg.norm(g)
 
 
+def _run_mc_world2(tmp_path, backend):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "mc")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_mc_dist_worker.py"), out,
+                                       backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o.decode()[-2000:]
+    return [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+
+
+def test_monte_carlo_sample_sharding_world2_gloo(tmp_path):
+    """Sample-index sharding of the Monte Carlo loop (the reference's process fan-out, :816-848): two
+    ranks' blocks together are the single-rank run, and the one exchanged scalar normalises the posterior
+    over all samples.  The device call is replaced by the oracle here (no GPU in this suite)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _mc_dist_worker as w
+    from full_waveform_inversion_amd import source_inversion as si
+    assert [si.partition_samples(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    res = _run_mc_world2(tmp_path, "oracle")
+    d, G, N, typ = w.problem()
+    M, frac, sim, like, post = w.oracle_invert(d, G, N, typ, 9, 0, 1.5, "VR", False, False)
+    assert (int(res[0]["first"]), int(res[1]["first"])) == (0, 501)
+    assert res[0]["M"].shape == (10, 501) and res[1]["M"].shape == (10, 500)
+    assert np.array_equal(np.hstack([r["M"] for r in res]), np.vstack((M, frac)))
+    assert np.array_equal(np.concatenate([r["like"] for r in res]), like)
+    allpost = np.concatenate([r["post"] for r in res])
+    assert abs(allpost.sum() - 1.0) < 1e-12 and np.allclose(allpost, post, rtol=1e-12, atol=0)
+
+
 def test_lbfgs_quadratic_and_rosenbrock():
     rng = np.random.default_rng(0)
     A = rng.standard_normal((20, 20))
