@@ -1298,6 +1298,8 @@ namespace fwi {
 hipError_t launch_mc_sample(int type, uint64_t seed, int64_t first, int64_t nsamp, double amplitude, double *Ms,
                             int64_t ld, double *frac, hipStream_t s);
 int mc_sampler_components(int type);
+hipError_t launch_mc_posterior(const double *like, int64_t n, double *scratch, double *post, hipStream_t s);
+int mc_posterior_scratch_doubles();
 hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,
                            int k, int n, int t, int64_t nsamp, int metric, int normalise, int all_at_once,
                            double gau_sigma, double *sim, double *like, hipStream_t s);
@@ -1445,20 +1447,14 @@ int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
     if (kernel_ms_out) *kernel_ms_out = ms;
     if (smp.samples_out) MCCHK(hipMemcpy(smp.samples_out, M.p, mb, hipMemcpyDeviceToHost));
     if (smp.frac_out) MCCHK(hipMemcpy(smp.frac_out, fr.p, sb, hipMemcpyDeviceToHost));
-    if (likelihood_out || posterior_out) {
-        std::vector<double> tmp;
-        double *L = likelihood_out;
-        if (!L) {
-            tmp.resize(nsamp);
-            L = tmp.data();
-        }
-        MCCHK(hipMemcpy(L, like.p, sb, hipMemcpyDeviceToHost));
-        if (posterior_out) {  // :847-848, p_model = 1/N
-            const double p_model = 1.0 / (double)nsamp;
-            double p_data = 0.0;
-            for (int64_t i = 0; i < nsamp; ++i) p_data += p_model * L[i];
-            for (int64_t i = 0; i < nsamp; ++i) posterior_out[i] = L[i] * p_model / p_data;
-        }
+    if (likelihood_out) MCCHK(hipMemcpy(likelihood_out, like.p, sb, hipMemcpyDeviceToHost));
+    if (posterior_out) {  // :847-848, p_model = 1/N; normalised on the device, `sim` reused for the result
+        DevBuf acc;
+        MCCHK(hipMalloc(&acc.p, (size_t)fwi::mc_posterior_scratch_doubles() * 8));
+        hipError_t pe = fwi::launch_mc_posterior((const double *)like.p, nsamp, (double *)acc.p, (double *)sim.p,
+                                                 nullptr);
+        if (pe != hipSuccess) return mc_fail(FWI_EHIP, "mc_posterior_kernel launch", pe);
+        MCCHK(hipMemcpy(posterior_out, sim.p, sb, hipMemcpyDeviceToHost));
     }
     return FWI_OK;
 }

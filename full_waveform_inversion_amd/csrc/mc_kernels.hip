@@ -14,6 +14,7 @@
 // moments (the synthetic is never written).  CC-shift uses the exact sums of the 4x linearly
 // interpolated sequences (np.interp clamps past the last sample), expressed through lag-1 products.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 namespace fwi {
@@ -450,6 +451,57 @@ __global__ __launch_bounds__(256) void mc_score_lanes(const double *__restrict__
         sim_out[smp] = sim;
         if (like_out) like_out[smp] = exp(-(1.0 - sim) / 2.0);  // :774
     }
+}
+
+// posterior normalisation (:847-848): p_data = sum_i p_model L_i, post_i = L_i p_model / p_data.
+// The sum is taken in a fixed order (per-block partials, then one block over the partials), so the
+// posterior is bitwise reproducible from run to run.
+constexpr int MC_SUM_BLOCKS = 1024;
+
+__device__ __forceinline__ double mc_block_sum(double s, double *part) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void mc_sum_like_kernel(const double *__restrict__ like, int64_t n, double p_model,
+                                                          double *__restrict__ partial) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s += p_model * like[i];
+    s = mc_block_sum(s, part);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void mc_sum_partials_kernel(double *__restrict__ partial, int nblocks) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    s = mc_block_sum(s, part);
+    if (threadIdx.x == 0) partial[MC_SUM_BLOCKS] = s;
+}
+
+__global__ __launch_bounds__(256) void mc_posterior_kernel(const double *__restrict__ like, int64_t n, double p_model,
+                                                           const double *__restrict__ partial,
+                                                           double *__restrict__ post) {
+    const double p_data = partial[MC_SUM_BLOCKS];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        post[i] = like[i] * p_model / p_data;
+}
+
+int mc_posterior_scratch_doubles() { return MC_SUM_BLOCKS + 1; }
+
+// post (device, n) from like (device, n); scratch = mc_posterior_scratch_doubles() device doubles
+hipError_t launch_mc_posterior(const double *like, int64_t n, double *scratch, double *post, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, MC_SUM_BLOCKS);
+    const double p_model = 1.0 / (double)n;
+    hipLaunchKernelGGL(mc_sum_like_kernel, dim3(blocks), dim3(256), 0, s, like, n, p_model, scratch);
+    hipLaunchKernelGGL(mc_sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, blocks);
+    hipLaunchKernelGGL(mc_posterior_kernel, dim3(blocks), dim3(256), 0, s, like, n, p_model, scratch, post);
+    return hipGetLastError();
 }
 
 // forward_model for a batch: synth[i, k, t] (full_waveform_inversion.py:253-264), same j order
