@@ -73,3 +73,61 @@ def remove_zero_prob_results(MTp, MTs):
     """Drop samples with zero posterior (:948-953)."""
     keep = np.asarray(MTp) > 0.0
     return np.asarray(MTp)[keep], np.asarray(MTs)[:, keep]
+
+
+def load_input_data(datadir, real_data_fnames, green_func_fnames, manual_indices_time_shift=(),
+                    cut_phase_start_vals=(), cut_phase_length=0, set_pre_time_shift_values_to_zero_switch=True):
+    """The reference's trace loader (:75-113): one whitespace text file per trace for the data
+    (``t`` values) and for the Green's functions (``t`` rows x ``n`` component columns).
+
+    Returns ``real_data_array (k, t)`` and ``green_func_array (k, n, t)``.  Optional per-trace
+    alignment: the Green's functions are rolled by ``manual_indices_time_shift[i]`` samples along
+    time (samples rolled in from the end are zeroed unless the switch is off), then a window
+    ``[start_i, start_i + cut_phase_length)`` is cut from both.
+    """
+    real = np.stack([np.loadtxt(os.path.join(datadir, f), dtype=float) for f in real_data_fnames])
+    green = np.stack([np.transpose(np.loadtxt(os.path.join(datadir, f), dtype=float)) for f in green_func_fnames])
+    if len(manual_indices_time_shift) > 0:
+        rolled = np.zeros_like(green)  # traces beyond the list keep zeros, as in the reference (:95-99)
+        for i, shift in enumerate(manual_indices_time_shift):
+            rolled[i] = np.roll(green[i], shift, axis=1)
+            if set_pre_time_shift_values_to_zero_switch:
+                rolled[i, :, 0:shift] = 0.0
+        green = rolled
+    if len(cut_phase_start_vals) > 0:
+        n = int(cut_phase_length)
+        real = np.stack([real[i, int(s):int(s) + n] for i, s in enumerate(cut_phase_start_vals)])
+        green = np.stack([green[i, :, int(s):int(s) + n] for i, s in enumerate(cut_phase_start_vals)])
+    return real, green
+
+
+def get_overall_real_and_green_func_data(datadir, real_data_fnames, MT_green_func_fnames,
+                                         single_force_green_func_fnames, inversion_type,
+                                         manual_indices_time_shift_MT=(), manual_indices_time_shift_SF=(),
+                                         cut_phase_start_vals=(), cut_phase_length=0,
+                                         set_pre_time_shift_values_to_zero_switch=True):
+    """Data and Green's functions for an inversion type (:168-197): moment-tensor files for the
+    6-component types, single-force files for ``single_force``, both side by side (9 components)
+    for the combined types; moment-tensor Green's functions are scaled by 1e3 (units relative to
+    the single-force ones) and everything by 1e7 (SI), as the reference does.  The reference's
+    two-media variant is not provided (it is unreachable from its shipped driver, SURVEY A-8/A-9).
+    """
+    kw = dict(cut_phase_start_vals=cut_phase_start_vals, cut_phase_length=cut_phase_length,
+              set_pre_time_shift_values_to_zero_switch=set_pre_time_shift_values_to_zero_switch)
+    if inversion_type in ("full_mt", "DC", "DC_crack_couple"):
+        real, green = load_input_data(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT,
+                                      **kw)
+        green = green * (10 ** 3)
+    elif inversion_type == "single_force":
+        real, green = load_input_data(datadir, real_data_fnames, single_force_green_func_fnames,
+                                      manual_indices_time_shift_SF, **kw)
+    elif inversion_type in ("DC_single_force_couple", "DC_single_force_no_coupling",
+                            "single_force_crack_no_coupling"):
+        real, mt = load_input_data(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT,
+                                   **kw)
+        real, sf = load_input_data(datadir, real_data_fnames, single_force_green_func_fnames,
+                                   manual_indices_time_shift_SF, **kw)
+        green = np.hstack((mt * (10 ** 3), sf))
+    else:
+        raise ValueError("unknown inversion_type %r" % (inversion_type,))
+    return real, green * (10 ** 7)

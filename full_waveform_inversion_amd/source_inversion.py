@@ -12,6 +12,7 @@ There is no CPU fallback: without the HIP library / a GPU these raise FwiError.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -211,3 +212,62 @@ def perform_monte_carlo_sampled_waveform_inversion_sharded(real_data_array, gree
     if return_samples and inversion_type in samplers.COUPLED_TYPES:
         M = np.vstack((M, frac))
     return first, M, like / total, like
+
+
+def perform_inversion(real_data_array, green_func_array):
+    """Least-squares source estimate (:242-251): stack the traces in time, solve ``G M = D``.
+    Returns ``M (n, 1)``.  Host-side (one small ``lstsq``); the reference uses it for the amplitude
+    ``|M|`` the Monte Carlo samples are scaled by (:1171-1172)."""
+    d, G = _f64(real_data_array), _f64(green_func_array)
+    D = d.reshape(-1, 1)                                  # [d_0; d_1; ...]
+    A = np.transpose(G, (0, 2, 1)).reshape(-1, G.shape[1])  # rows (trace, time), columns = components
+    return np.linalg.lstsq(A, D, rcond=-1)[0]             # rcond=-1: the legacy default the reference ran with
+
+
+def get_synth_forward_model_most_likely_result(MTs, MTp, green_func_array, inversion_type, device=0):
+    """Synthetic of the highest-posterior sample (:974-1020, single-medium branches): the coupled
+    types carry the amplitude fraction as an extra last row, which is not a source component."""
+    best = int(np.where(MTp == np.max(MTp))[0][0])
+    rows = slice(None, -1) if inversion_type in samplers.COUPLED_TYPES else slice(None)
+    return forward_model(green_func_array, np.asarray(MTs)[rows, best], device)
+
+
+def run(datadir, outdir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, data_labels,
+        inversion_type, perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously, num_samples,
+        comparison_metric, manual_indices_time_shift_MT=(), manual_indices_time_shift_SF=(), uid="event",
+        stations=(), cut_phase_start_vals=(), cut_phase_length=0, set_pre_time_shift_values_to_zero_switch=True,
+        only_save_non_zero_solns_switch=False, return_absolute_similarity_values_switch=False, seed=0, device=0,
+        reference_stream=False):
+    """The reference's ``run`` (:1161-1233) for one set of Green's functions: load the traces,
+    least-squares estimate (saved under ``<outdir>/least_squares_result``), Monte Carlo inversion
+    on the GPU scaled to the least-squares amplitude, result and best-fit waveforms pickled in the
+    reference's layout.  ``uid`` / ``stations`` replace the NonLinLoc file the reference reads them
+    from (needs obspy); plotting is left to the reference's plotting script, which reads the
+    files written here.  Returns ``(MTs, MTp, MTp_absolute)``.
+    """
+    from . import io
+    real, G = io.get_overall_real_and_green_func_data(
+        datadir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, inversion_type,
+        manual_indices_time_shift_MT, manual_indices_time_shift_SF, cut_phase_start_vals, cut_phase_length,
+        set_pre_time_shift_values_to_zero_switch)
+    M = perform_inversion(real, G)
+    M_amplitude = float(np.sum(M ** 2) ** 0.5)
+    lsq_sim = compare_synth_to_real_waveforms(real, G, M, comparison_metric, perform_normallised_waveform_inversion,
+                                              compare_all_waveforms_simultaneously, device)
+    lsq_dir = os.path.join(outdir, "least_squares_result")
+    io.save_to_MTFIT_style_file(M, np.array([lsq_sim]), uid, inversion_type, lsq_dir, stations)
+    # the reference slices MTs[:-1] here for the coupled types although the least-squares M has no
+    # fraction row (SURVEY Appendix A-10); the full M is used instead
+    io.save_specific_waveforms_to_file(real, forward_model(G, M, device), data_labels, uid, inversion_type, lsq_dir)
+    MTs, MTp, MTp_absolute = perform_monte_carlo_sampled_waveform_inversion(
+        real, G, num_samples, M_amplitude, inversion_type, comparison_metric, perform_normallised_waveform_inversion,
+        compare_all_waveforms_simultaneously, seed=seed, device=device, reference_stream=reference_stream,
+        return_absolute_similarity_values_switch=return_absolute_similarity_values_switch)
+    if np.isnan(MTp[0]):
+        raise FloatingPointError("sum of probabilities is zero: no adequate solution found (:1208-1210)")
+    if only_save_non_zero_solns_switch:
+        MTp, MTs = io.remove_zero_prob_results(MTp, MTs)
+    io.save_to_MTFIT_style_file(MTs, MTp, uid, inversion_type, outdir, stations, MTp_absolute)
+    best = get_synth_forward_model_most_likely_result(MTs, MTp, G, inversion_type, device)
+    io.save_specific_waveforms_to_file(real, best, data_labels, uid, inversion_type, outdir)
+    return MTs, MTp, MTp_absolute

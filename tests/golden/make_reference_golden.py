@@ -18,6 +18,11 @@ inversion_type (:740-760, :852-853): after np.random.seed(s); random.seed(s) eac
 called 48 times and its outputs kept, and the one-process driver is run per type on a small
 seeded problem.
 
+ref_pipeline.npz pins the host functions either side of the loop: load_input_data (:75-113),
+get_overall_real_and_green_func_data (:168-197), perform_inversion (:242-251) and
+get_synth_forward_model_most_likely_result (:974-1020), run on text trace files written to a
+temporary directory from the seeded arrays stored alongside the outputs.
+
 Run from the repo root (only where /root/reference exists):
     python tests/golden/make_reference_golden.py
 """
@@ -169,8 +174,68 @@ def samplers_case(ref, name, nsamp=48, ndrv=40):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def write_trace_files(datadir, real, mt, sf):
+    """One text file per trace, in the layout load_input_data (:75-113) reads: data = t values,
+    Green's functions = t rows x n component columns.  Returns the three file-name lists."""
+    names = ([], [], [])
+    for i in range(real.shape[0]):
+        for lst, stem, arr in ((names[0], "real_%02d.txt", real[i]), (names[1], "gf_mt_%02d.txt", mt[i].T),
+                               (names[2], "gf_sf_%02d.txt", sf[i].T)):
+            lst.append(stem % i)
+            np.savetxt(os.path.join(datadir, stem % i), arr, fmt="%.18e")
+    return names
+
+
+def pipeline_case(ref, name):
+    """The host functions either side of the loop: trace loading with time shift / phase cut and the
+    unit scalings (:75-113, :168-197), the least-squares estimate (:242-251) and the best-sample
+    synthetic (:974-1020)."""
+    import tempfile
+    rng = np.random.default_rng(77)
+    k, t = 5, 120
+    real = rng.standard_normal((k, t))
+    mt = rng.standard_normal((k, 6, t)) * 1e-10
+    sf = rng.standard_normal((k, 3, t)) * 1e-7
+    out = {"real": real, "mt": mt, "sf": sf}
+    shift_mt, shift_sf = [3, 0, 7, 1, 12], [2, 5, 0, 9, 4]
+    cut_start, cut_len = [10, 0, 33, 20, 58], 60
+    out["shift_mt"], out["shift_sf"], out["cut_start"], out["cut_len"] = shift_mt, shift_sf, cut_start, cut_len
+    with tempfile.TemporaryDirectory() as tmp:
+        rn, mn, sn = write_trace_files(tmp, real, mt, sf)
+        out["plain_real"], out["plain_green"] = ref.load_input_data(tmp, rn, mn)
+        out["shift_real"], out["shift_green"] = ref.load_input_data(tmp, rn, mn, shift_mt)
+        out["shiftkeep_real"], out["shiftkeep_green"] = ref.load_input_data(
+            tmp, rn, mn, shift_mt, set_pre_time_shift_values_to_zero_switch=False)
+        out["cut_real"], out["cut_green"] = ref.load_input_data(tmp, rn, sn, shift_sf, cut_start, cut_len)
+        for typ in SAMPLERS:
+            r, g = ref.get_overall_real_and_green_func_data(
+                tmp, rn, mn, sn, typ, manual_indices_time_shift_MT=shift_mt, manual_indices_time_shift_SF=shift_sf,
+                cut_phase_start_vals=cut_start, cut_phase_length=cut_len)
+            out["overall_real_" + typ], out["overall_green_" + typ] = r, g
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out["lsq_" + typ] = ref.perform_inversion(r, g)
+            # most likely synthetic from a small set of samples with a known best one
+            np.random.seed(5)
+            random.seed(5)
+            cols, fr = [], []
+            for _ in range(6):
+                smp = getattr(ref, SAMPLERS[typ])()
+                cols.append(smp[0] if isinstance(smp, tuple) else smp)
+                fr.append(smp[1] if isinstance(smp, tuple) else 0.0)
+            MTs = np.hstack(cols)
+            if isinstance(smp, tuple):
+                MTs = np.vstack((MTs, np.array(fr)))
+            MTp = np.array([0.1, 0.05, 0.4, 0.2, 0.15, 0.1])
+            out["ml_MTs_" + typ], out["ml_MTp_" + typ] = MTs, MTp
+            out["ml_synth_" + typ] = ref.get_synth_forward_model_most_likely_result(MTs, MTp, g, typ)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "written:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ref = load_reference()
+    pipeline_case(ref, "ref_pipeline")
     samplers_case(ref, "ref_samplers")
     case(ref, "ref_mc_fullmt", 0, 5, 6, 160, 24, "full_mt")
     case(ref, "ref_mc_force", 1, 21, 3, 100, 16, "single_force")
