@@ -72,8 +72,9 @@ int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
         gerr = "fwi_mc_score: bad metric or null output";
         return FWI_EINVAL;
     }
-    if (fwi::mc_score_lds_bytes(k, n) > 64 * 1024) {
-        gerr = "fwi_mc_score: k * n too large for the per-workgroup moment table";
+    const bool lane_kernel = n == 3 || n == 6 || n == 9;  // keeps everything in registers: no limit on k
+    if (!lane_kernel && fwi::mc_score_lds_bytes(k, n) > 64 * 1024) {
+        gerr = std::string(fn) + ": k * n too large for the moment kernel's per-workgroup table";
         return FWI_EINVAL;
     }
     MCCHK(hipSetDevice(device));

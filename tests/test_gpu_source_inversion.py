@@ -205,3 +205,23 @@ def test_errors(gpu):
         si.score_samples(d, G, np.ones((3, 5)), "nope")
     with pytest.raises(FwiError):
         si.score_samples(d, G, np.ones((3, 5)), device=99)
+    with pytest.raises(ValueError):
+        si.sample_on_device("nope", 4)
+    with pytest.raises(FwiError):
+        si.sample_on_device("DC", 0)
+    with pytest.raises(FwiError):
+        si.sample_on_device("DC", 4, first_sample=-1)
+    with pytest.raises(FwiError, match="too large"):   # the moment kernel (n = 5) keeps k * n moments in LDS ...
+        si.score_samples(np.ones((400, 8)), np.ones((400, 5, 8)), np.ones((5, 3)))
+
+
+def test_many_traces_take_the_lane_kernel_without_an_lds_limit(gpu):
+    """... the lane-per-sample kernel (n = 3 / 6 / 9) has no such limit."""
+    rng = np.random.default_rng(2)
+    k, n, t, N = 400, 3, 16, 70
+    G = rng.standard_normal((k, n, t))
+    Ms = rng.standard_normal((n, N))
+    d = np.einsum("kjt,j->kt", G, Ms[:, 1]) + 0.2 * rng.standard_normal((k, t))
+    sim = si.score_samples(d, G, Ms, "PCC", True, False)[0]
+    ref = mo.score_samples(G, d, Ms, "PCC", True, False)[0]
+    assert np.allclose(sim, ref, rtol=1e-9, atol=1e-12)
