@@ -10,7 +10,6 @@
 #include "../../include/fwi.h"
 #include "mc_kernels.h"
 
-
 namespace {
 
 // `gerr = text` sets the text fwi_last_error(NULL) returns (owned by fwi_api.hip)
@@ -21,6 +20,11 @@ const struct {
 struct DevBuf {  // frees on scope exit
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct Event {  // destroyed on scope exit
+    hipEvent_t e = nullptr;
+    ~Event() { if (e) (void)hipEventDestroy(e); }
 };
 
 int mc_fail(int code, const char *what, hipError_t e) {
@@ -139,20 +143,18 @@ int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
         MCCHK(hipMemcpy(M.p, samples, mb, hipMemcpyHostToDevice));
     }
     MCCHK(hipMemcpy(dm.p, dmom.data(), dmom.size() * 8, hipMemcpyHostToDevice));
-    hipEvent_t e0, e1;
-    MCCHK(hipEventCreate(&e0));
-    MCCHK(hipEventCreate(&e1));
-    MCCHK(hipEventRecord(e0, s));
+    Event e0, e1;
+    MCCHK(hipEventCreate(&e0.e));
+    MCCHK(hipEventCreate(&e1.e));
+    MCCHK(hipEventRecord(e0.e, s));
     hipError_t le = fwi::launch_mc_score((const double *)G.p, (const double *)Gt.p, (const double *)d.p, (const double *)M.p,
                                          (const double *)dm.p, k, n, t, nsamp, metric, normalise != 0,
                                          all_at_once != 0, sigma, (double *)sim.p, (double *)like.p, s);
     if (le != hipSuccess) return mc_fail(FWI_EHIP, "mc_score_kernel launch", le);
-    MCCHK(hipEventRecord(e1, s));
+    MCCHK(hipEventRecord(e1.e, s));
     MCCHK(hipMemcpy(similarity_out, sim.p, sb, hipMemcpyDeviceToHost));
     float ms = 0.f;
-    MCCHK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    MCCHK(hipEventElapsedTime(&ms, e0.e, e1.e));
     if (kernel_ms_out) *kernel_ms_out = ms;
     if (smp.samples_out) MCCHK(hipMemcpy(smp.samples_out, M.p, mb, hipMemcpyDeviceToHost));
     if (smp.frac_out) MCCHK(hipMemcpy(smp.frac_out, fr.p, sb, hipMemcpyDeviceToHost));
