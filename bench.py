@@ -117,8 +117,25 @@ def main():
         try:
             ids = [Engine.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            e.comm_init(rank, world, ids[0])
-            ok, why = 1, ""
+            # ncclCommInitRank in a helper thread (ctypes drops the GIL): a communicator that neither
+            # comes up nor fails within the limit is treated like one that failed
+            import threading
+            res = {}
+
+            def init():
+                try:
+                    e.comm_init(rank, world, ids[0])
+                    res["ok"] = True
+                except FwiError as ex:
+                    res["err"] = str(ex)
+
+            th = threading.Thread(target=init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("FWI_COMM_INIT_TIMEOUT", "180")))
+            if res.get("ok"):
+                ok, why = 1, ""
+            else:
+                ok, why = 0, res.get("err", "ncclCommInitRank did not return within the time limit")
         except FwiError as ex:
             ok, why = 0, str(ex)
         import torch
