@@ -79,6 +79,17 @@ def compare_synth_to_real_waveforms(real_data_array, green_func_array, M, compar
                                device)[0][0])
 
 
+def get_unnormallised_prob_for_specific_soln(real_data_array, green_func_array, MT_specific_soln, comparison_metric,
+                                            perform_normallised_waveform_inversion=True,
+                                            compare_all_waveforms_simultaneously=True, device=0):
+    """Unnormalised probability (= similarity) of one given solution: the core of the reference's
+    third script (unnormallised_probability_retrieval_from_full_waveform_soln.py:222-232), i.e.
+    forward model + comparison, both on the GPU."""
+    return compare_synth_to_real_waveforms(real_data_array, green_func_array, MT_specific_soln, comparison_metric,
+                                           perform_normallised_waveform_inversion,
+                                           compare_all_waveforms_simultaneously, device)
+
+
 def sample_on_device(inversion_type, num_samples, seed=0, first_sample=0, M_amplitude=1.0, device=0):
     """``num_samples`` sources of ``inversion_type`` drawn by the device sampler (``fwi_mc_sample``):
     the reference's generate_random_* maps (:282-510) applied to counter-based deviates, sample

@@ -197,6 +197,13 @@ def test_million_samples_best_is_truth(gpu):
     assert N / (ms * 1e-3) > 1e6  # the reference manages ~1e3 samples/s per core
 
 
+def test_unnormalised_probability_of_a_given_solution(gpu):
+    z = np.load(os.path.join(GOLDEN, "ref_mc_fullmt.npz"))
+    for i in (0, 7, 23):
+        p = si.get_unnormallised_prob_for_specific_soln(z["d"], z["G"], z["M"][:, i:i + 1], "VR", True, False)
+        assert abs(p - z["sim_VR_n1_a0"][i]) <= TOL
+
+
 def test_errors(gpu):
     G, d = np.ones((2, 3, 8)), np.ones((2, 8))
     with pytest.raises(ValueError):
