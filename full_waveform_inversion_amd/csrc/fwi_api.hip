@@ -55,6 +55,7 @@ struct fwi_ctx {
     void *c_dev = nullptr;            // compact velocity
     void *dz = nullptr, *dy = nullptr, *dx = nullptr;
     void *q_store = nullptr;  // nt_max x npts forward terms
+    void *logical = nullptr;  // nz x ny x nx staging array for host <-> compact copies when cx != nx
     void *g_acc = nullptr;    // compact gradient accumulator
     void *g_out = nullptr;    // compact scratch for fwi_gradient
     double *red = nullptr;    // reduction scalars
@@ -199,7 +200,7 @@ int flatten(fwi_ctx *ctx, const int32_t *idx, int n, std::vector<int64_t> &pidx,
         if (z < 0 || z >= g.nz || y < 0 || y >= g.ny || x < 0 || x >= g.nx)
             return ctx->fail(FWI_EINVAL, "grid index %d outside the grid", i);
         pidx[i] = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
-        cidx[i] = ((int64_t)z * g.ny + y) * g.nx + x;
+        cidx[i] = ((int64_t)z * g.ny + y) * g.cx + x;
     }
     return FWI_OK;
 }
@@ -244,12 +245,40 @@ struct Impl {
         return a;
     }
 
-    static int set_model(fwi_ctx *ctx, const T *c) {
+    // Host arrays are model-shaped (row stride nx); compact device arrays have row stride cx (nx
+    // rounded up to 4, pad columns zero).  Equal for nx % 4 == 0: one plain copy.  Otherwise the
+    // contiguous array goes through a device staging buffer and a repack kernel.
+    static int upload_compact(fwi_ctx *ctx, void *dst, const void *host) {
         const GridDesc &g = ctx->gd;
-        hipStream_t s = ctx->stream;
+        if (g.cx == g.nx) {
+            HIPCHK(ctx, hipMemcpyAsync(dst, host, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            return FWI_OK;
+        }
+        const size_t nlog = (size_t)g.nz * g.ny * g.nx;
+        if (!ctx->logical) HIPCHK(ctx, hipMalloc(&ctx->logical, nlog * sizeof(T)));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->logical, host, nlog * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, launch_repack<T>(g, (T *)dst, (const T *)ctx->logical, 1, ctx->stream));
+        return FWI_OK;
+    }
+
+    static int download_compact(fwi_ctx *ctx, void *host, const void *src) {
+        const GridDesc &g = ctx->gd;
+        if (g.cx == g.nx) {
+            HIPCHK(ctx, hipMemcpyAsync(host, src, (size_t)g.npts * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            return FWI_OK;
+        }
+        const size_t nlog = (size_t)g.nz * g.ny * g.nx;
+        if (!ctx->logical) HIPCHK(ctx, hipMalloc(&ctx->logical, nlog * sizeof(T)));
+        HIPCHK(ctx, launch_repack<T>(g, (T *)ctx->logical, (const T *)src, 0, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(host, ctx->logical, nlog * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        return FWI_OK;
+    }
+
+    static int set_model(fwi_ctx *ctx, const T *c) {
         // compact H2D copy, then validation + padded C = dt^2 c^2 on the device (the halo of C
         // was zeroed at creation and is never written)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->c_dev, c, (size_t)g.npts * sizeof(T), hipMemcpyHostToDevice, s));
+        int rc = upload_compact(ctx, ctx->c_dev, c);
+        if (rc) return rc;
         return finish_model(ctx);
     }
 
@@ -808,8 +837,8 @@ struct Impl {
 
     static int gradient_vec(fwi_ctx *ctx, int32_t wrt, void *dev) {
         const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
-        HIPCHK(ctx, launch_finalize_gradient<T>((const T *)ctx->g_acc, (const T *)ctx->c_dev, (T *)dev, scale,
-                                                wrt == FWI_WRT_VELOCITY, ctx->gd.npts, ctx->stream));
+        HIPCHK(ctx, launch_finalize_gradient<T>(ctx->gd, (const T *)ctx->g_acc, (const T *)ctx->c_dev, (T *)dev, scale,
+                                                wrt == FWI_WRT_VELOCITY, ctx->stream));
         return FWI_OK;
     }
 
@@ -835,18 +864,17 @@ struct Impl {
     }
 
     static int vec_clip(fwi_ctx *ctx, void *x, double lo, double hi) {
-        HIPCHK(ctx, launch_clip<T>((T *)x, lo, hi, ctx->gd.npts, ctx->stream));
+        HIPCHK(ctx, launch_clip<T>(ctx->gd, (T *)x, lo, hi, ctx->stream));
         return FWI_OK;
     }
 
     static int gradient(fwi_ctx *ctx, int32_t wrt, T *out) {
         const GridDesc &g = ctx->gd;
         const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
-        HIPCHK(ctx, launch_finalize_gradient<T>((const T *)ctx->g_acc, (const T *)ctx->c_dev,
-                                                (T *)ctx->g_out, scale, wrt == FWI_WRT_VELOCITY,
-                                                g.npts, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(out, ctx->g_out, (size_t)g.npts * sizeof(T), hipMemcpyDeviceToHost,
-                                   ctx->stream));
+        HIPCHK(ctx, launch_finalize_gradient<T>(g, (const T *)ctx->g_acc, (const T *)ctx->c_dev,
+                                                (T *)ctx->g_out, scale, wrt == FWI_WRT_VELOCITY, ctx->stream));
+        int rc = download_compact(ctx, out, ctx->g_out);
+        if (rc) return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return FWI_OK;
     }
@@ -976,7 +1004,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
-        return bad("STREAM kernel needs nx % 4 == 0 (fp32) or a 3-D grid with nx % 2 == 0 (fp64)");
+        return bad("STREAM kernel: fp64 is 3-D only");
     }
     ctx->kernel = (cfg->kernel == FWI_KERNEL_POINT || !can_stream) ? K_POINT : K_STREAM;
     if (ctx->kernel == K_STREAM) {
@@ -1018,7 +1046,7 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
                     ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series, ctx->wav, ctx->snap, ctx->fwd[0],
-                    ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1]};
+                    ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1], ctx->logical};
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
                         ps->s_cq, ps->s_col, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,
@@ -1148,7 +1176,8 @@ int fwi_vec_upload(fwi_ctx *ctx, int32_t slot, const void *host) {
     VEC_OR_FAIL(ctx, v, slot);
     if (!host) return ctx->fail(FWI_EINVAL, "fwi_vec_upload: null buffer");
     (void)hipSetDevice(ctx->cfg.device);
-    HIPCHK(ctx, hipMemcpyAsync(v, host, (size_t)ctx->gd.npts * ctx->esize, hipMemcpyHostToDevice, ctx->stream));
+    int rc = DISPATCH(ctx, Impl<float>::upload_compact(ctx, v, host), Impl<double>::upload_compact(ctx, v, host));
+    if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FWI_OK;
 }
@@ -1158,7 +1187,8 @@ int fwi_vec_download(fwi_ctx *ctx, int32_t slot, void *host) {
     VEC_OR_FAIL(ctx, v, slot);
     if (!host) return ctx->fail(FWI_EINVAL, "fwi_vec_download: null buffer");
     (void)hipSetDevice(ctx->cfg.device);
-    HIPCHK(ctx, hipMemcpyAsync(host, v, (size_t)ctx->gd.npts * ctx->esize, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = DISPATCH(ctx, Impl<float>::download_compact(ctx, host, v), Impl<double>::download_compact(ctx, host, v));
+    if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FWI_OK;
 }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 qv[i] = nt4{0.f, 0.f, 0.f, 0.f};
                 if (interior && inside[i] == 0xF)
                     qv[i] = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(
-                        a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.nx + (x0 + 4 * l4)));
+                        a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4)));
             }
         }
         // ---- stencil update ---------------------------------------------------------------------------
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
             if (SAVE_Q) {
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
                 if (interior && inside[i]) {
-                    float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.nx + (x0 + 4 * l4);
+                    float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
                     if (inside[i] == 0xF) {
                         nt4 v = {q.v[0], q.v[1], q.v[2], q.v[3]};
                         __builtin_nontemporal_store(v, reinterpret_cast<nt4 *>(qp));
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 const int lz = gi / E4, l4 = gi % E4;
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
                 if (interior && inside[i]) {
-                    const float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.nx + (x0 + 4 * l4);
+                    const float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
                     const q4 u = prv[lz][l4];
                     if (inside[i] == 0xF) {
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
             *reinterpret_cast<q4 *>(a.out_cur + p) = vc;
             *reinterpret_cast<q4 *>(a.out_prev + p) = vp;
             if (IMAGE) {
-                float *gp = a.g + (int64_t)z * g.nx + x;
+                float *gp = a.g + (int64_t)z * g.cx + x;
                 q4 gv = *reinterpret_cast<const q4 *>(gp);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gv.v[j] += gacc[i].v[j];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 if ((inside[i] >> j) & 1u) {
                     a.out_cur[p + j] = vc.v[j];
                     a.out_prev[p + j] = vp.v[j];
-                    if (IMAGE) a.g[(int64_t)z * g.nx + x + j] += gacc[i].v[j];
+                    if (IMAGE) a.g[(int64_t)z * g.cx + x + j] += gacc[i].v[j];
                 }
         }
     }

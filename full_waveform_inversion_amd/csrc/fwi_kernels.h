@@ -21,11 +21,13 @@ constexpr int LOOKAHEAD = 4;
 // off0 + z*sz + y*sy + x.  2-D grids are ny = 1 with no y halo (sz == sy).
 struct GridDesc {
     int ndim, nz, ny, nx;
+    int cx;          // row stride of COMPACT arrays: nx rounded up to 4, so that rows stay 16-byte
+                     // aligned for any nx; the cx - nx pad columns hold zeros
     int r;           // stencil radius (order / 2)
     int64_t sy, sz;  // padded strides in elements (x stride is 1)
     int64_t off0;    // padded offset of interior point (0, 0, 0)
     int64_t ptot;    // elements of one padded field
-    int64_t npts;    // nz * ny * nx
+    int64_t npts;    // nz * ny * cx: elements of one compact array (pad columns included)
 };
 
 GridDesc make_grid(int ndim, int nz, int ny, int nx, int order);
@@ -93,10 +95,13 @@ hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n
 // g[i] += u(center of point i) * q[i] over the whole grid (last imaging step)
 template <typename T>
 hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipStream_t s);
-// out[i] = gacc[i] * scale * (wrt_velocity ? -2 / c[i]^3 : 1)
+// out[i] = gacc[i] * scale * (wrt_velocity ? -2 / c[i]^3 : 1); 0 in the pad columns
 template <typename T>
-hipError_t launch_finalize_gradient(const T *gacc, const T *c, T *out, double scale,
-                                    int wrt_velocity, int64_t n, hipStream_t s);
+hipError_t launch_finalize_gradient(const GridDesc &g, const T *gacc, const T *c, T *out, double scale,
+                                    int wrt_velocity, hipStream_t s);
+// compact (row stride cx, pad zeroed) <-> contiguous (row stride nx) copies on the device
+template <typename T>
+hipError_t launch_repack(const GridDesc &g, T *dst, const T *src, int to_compact, hipStream_t s);
 // Cpad (padded, halo untouched) = dt2 * c^2 from the compact velocity c; *bad += #invalid entries
 template <typename T>
 hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2, int *bad, hipStream_t s);
@@ -138,8 +143,9 @@ hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s
 // optimiser vector algebra: y = a x + b y; clamp; *out = max(*out, max|x|) (out zeroed by the caller)
 template <typename T>
 hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStream_t s);
+// clamps the grid points only (pad columns of a compact array stay zero)
 template <typename T>
-hipError_t launch_clip(T *x, double lo, double hi, int64_t n, hipStream_t s);
+hipError_t launch_clip(const GridDesc &g, T *x, double lo, double hi, hipStream_t s);
 template <typename T>
 hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s);
 

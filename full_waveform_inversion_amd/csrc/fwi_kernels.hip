@@ -37,7 +37,8 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     // 3-D: LOOKAHEAD extra zero planes behind the far z halo, so the stream kernel's prefetches of
     // planes z + r + 1 ... need no clamping (affine addresses: the plane offsets strength-reduce).
     g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO);
-    g.npts = (int64_t)nz * g.ny * nx;
+    g.cx = (int)round_up(nx, 4);
+    g.npts = (int64_t)nz * g.ny * g.cx;
     return g;
 }
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
             un = (T(2) * uc - up) + q;
         }
         a.u_prev[p] = un;
-        const int64_t ci = ((int64_t)z * g.ny + y) * g.nx + x;
+        const int64_t ci = ((int64_t)z * g.ny + y) * g.cx + x;
         if (SAVE_Q) a.q_out[ci] = q;
         if (IMAGE) a.g[ci] += a.q_in2 ? fma(up, a.q_in2[ci], uc * a.q_in[ci]) : uc * a.q_in[ci];
     }
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
     // same padded layout).
     const unsigned poff = (unsigned)(g.off0 + (int64_t)y * sy + x0);  // (z = 0, y, x0)
-    const unsigned coff = (unsigned)((int64_t)y * g.nx + x0);         // compact, z = 0
-    const int64_t cplane = (int64_t)g.ny * g.nx;
+    const unsigned coff = (unsigned)((int64_t)y * g.cx + x0);         // compact, z = 0
+    const int64_t cplane = (int64_t)g.ny * g.cx;
 
     // The loop below is free of divergent branches so that hipcc can count its
     // s_waitcnt vmcnt(N) exactly and keep the prefetches in flight across
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : lane;
     const float edge = a.u_cur[eoff];
     const f4 up = ld4(a.u_prev + poff), Cc = ld4(a.C + poff);
-    const int64_t ci = (int64_t)z * g.nx + x0;
+    const int64_t ci = (int64_t)z * g.cx + x0;
     f4 qi, qi2, gi;
     if (IMAGE) {
         qi = ld4_stream(a.q_in + (act ? ci : 0));
@@ -566,8 +567,10 @@ int stream_num_tiles(const GridDesc &g, const StreamTuning &t) {
 
 bool stream_supported(const GridDesc &g, bool is_f32) {
     if (g.nz < 1) return false;
-    if (is_f32) return g.nx % 4 == 0;         // float4 lanes (3-D stream kernel, 2-D tile kernel)
-    return g.ndim == 3 && g.nx % 2 == 0;      // double2 lanes: 3-D stream kernel only
+    // any nx: the padded fields and the compact arrays (row stride cx = nx rounded up to 4) keep every
+    // lane's 16-byte vector aligned; lanes straddling x = nx compute zeros there (C = 0 in the pad)
+    if (is_f32) return true;                  // float4 lanes (3-D stream kernel, 2-D tile kernel)
+    return g.ndim == 3;                       // double2 lanes: 3-D stream kernel only
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
@@ -777,11 +780,12 @@ hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void image_kernel(GridDesc g, const T *u, const T *q, T *gacc) {
-    const int64_t rowlen = g.nx;
+    const int64_t rowlen = g.cx;
     for (int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ci < g.npts;
          ci += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = ci / rowlen;  // z * ny + y
         const int x = (int)(ci - row * rowlen);
+        if (x >= g.nx) continue;  // pad column of the compact layout
         const int z = (int)(row / g.ny), y = (int)(row % g.ny);
         const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
         gacc[ci] += u[p] * q[ci];
@@ -800,8 +804,9 @@ template <typename T>
 __global__ void build_model_kernel(GridDesc g, const T *c, T *Cpad, double dt2, int *bad) {
     for (int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ci < g.npts;
          ci += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = ci / g.nx;
-        const int x = (int)(ci - row * g.nx);
+        const int64_t row = ci / g.cx;
+        const int x = (int)(ci - row * g.cx);
+        if (x >= g.nx) continue;  // pad column: C stays 0 there, which freezes u at 0 (a Dirichlet wall)
         const int z = (int)(row / g.ny), y = (int)(row % g.ny);
         const double cv = (double)c[ci];
         if (!(cv > 0.0) || !isfinite(cv)) atomicAdd(bad, 1);
@@ -818,7 +823,7 @@ hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2
 
 template <typename T>
 __global__ void finalize_gradient_kernel(const T *gacc, const T *c, T *out, double scale,
-                                         int wrt_velocity, int64_t n) {
+                                         int wrt_velocity, int64_t n, int nx, int cx) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         double v = (double)gacc[i] * scale;
@@ -826,16 +831,39 @@ __global__ void finalize_gradient_kernel(const T *gacc, const T *c, T *out, doub
             const double cc = (double)c[i];
             v *= -2.0 / (cc * cc * cc);
         }
+        if (cx != nx && (int)(i % cx) >= nx) v = 0.0;  // pad column (c = 0 there)
         out[i] = (T)v;
     }
 }
 
 template <typename T>
-hipError_t launch_finalize_gradient(const T *gacc, const T *c, T *out, double scale, int wrt_velocity,
-                                    int64_t n, hipStream_t s) {
-    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+hipError_t launch_finalize_gradient(const GridDesc &g, const T *gacc, const T *c, T *out, double scale,
+                                    int wrt_velocity, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (g.npts + 255) / 256));
     hipLaunchKernelGGL(finalize_gradient_kernel<T>, dim3(blocks), dim3(256), 0, s, gacc, c, out, scale,
-                       wrt_velocity, n);
+                       wrt_velocity, g.npts, g.nx, g.cx);
+    return hipGetLastError();
+}
+
+// compact (stride cx, pad columns zeroed) <-> contiguous (stride nx)
+template <typename T>
+__global__ void repack_kernel(T *dst, const T *src, int64_t rows, int nx, int cx, int to_compact) {
+    const int64_t n = rows * cx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cx;
+        const int x = (int)(i - row * cx);
+        if (to_compact)
+            dst[i] = x < nx ? src[row * nx + x] : T(0);
+        else if (x < nx)
+            dst[row * nx + x] = src[i];
+    }
+}
+
+template <typename T>
+hipError_t launch_repack(const GridDesc &g, T *dst, const T *src, int to_compact, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (g.npts + 255) / 256));
+    hipLaunchKernelGGL(repack_kernel<T>, dim3(blocks), dim3(256), 0, s, dst, src, (int64_t)g.nz * g.ny, g.nx, g.cx,
+                       to_compact);
     return hipGetLastError();
 }
 
@@ -870,9 +898,9 @@ __global__ void axpby_kernel(T *y, double a, const T *x, double b, int64_t n) {
 }
 
 template <typename T>
-__global__ void clip_kernel(T *x, double lo, double hi, int64_t n) {
+__global__ void clip_kernel(T *x, double lo, double hi, int64_t n, int nx, int cx) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        x[i] = (T)fmin(fmax((double)x[i], lo), hi);
+        if (cx == nx || (int)(i % cx) < nx) x[i] = (T)fmin(fmax((double)x[i], lo), hi);
 }
 
 // *out = max(*out, max |x|): wave64 shuffle max, LDS across waves, one atomic per block.  The
@@ -901,8 +929,8 @@ hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStre
     return hipGetLastError();
 }
 template <typename T>
-hipError_t launch_clip(T *x, double lo, double hi, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(clip_kernel<T>, dim3(vec_blocks(n)), dim3(256), 0, s, x, lo, hi, n);
+hipError_t launch_clip(const GridDesc &g, T *x, double lo, double hi, hipStream_t s) {
+    hipLaunchKernelGGL(clip_kernel<T>, dim3(vec_blocks(g.npts)), dim3(256), 0, s, x, lo, hi, g.npts, g.nx, g.cx);
     return hipGetLastError();
 }
 template <typename T>
@@ -914,12 +942,13 @@ hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
 #define FWI_INSTANTIATE(T)                                                                          \
     template hipError_t launch_record<T>(const T *, const int64_t *, T *, T, int, hipStream_t);    \
     template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
-    template hipError_t launch_finalize_gradient<T>(const T *, const T *, T *, double, int, int64_t, \
+    template hipError_t launch_finalize_gradient<T>(const GridDesc &, const T *, const T *, T *, double, int, \
                                                     hipStream_t);                                  \
+    template hipError_t launch_repack<T>(const GridDesc &, T *, const T *, int, hipStream_t);       \
     template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
     template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t); \
     template hipError_t launch_axpby<T>(T *, double, const T *, double, int64_t, hipStream_t);         \
-    template hipError_t launch_clip<T>(T *, double, double, int64_t, hipStream_t);                    \
+    template hipError_t launch_clip<T>(const GridDesc &, T *, double, double, hipStream_t);           \
     template hipError_t launch_absmax<T>(const T *, int64_t, double *, hipStream_t);
 FWI_INSTANTIATE(float)
 FWI_INSTANTIATE(double)

@@ -106,6 +106,32 @@ def test_stream_kernel_matches_point_kernel(gpu, zchunk, dtype, tol):
     assert rel(b["seis"], a["seis"]) < tol
 
 
+@pytest.mark.parametrize("shape,dtype,kern,tol", [((18, 21, 37), "float32", "step3d_stream", TOL32),
+                                                  ((18, 21, 37), "float64", "step3d_stream", TOL64),
+                                                  ((14, 9, 261), "float32", "step3d_stream", TOL32),
+                                                  ((40, 131), "float32", "step2d_", TOL32)])
+def test_stream_kernels_take_any_nx(gpu, shape, dtype, kern, tol):
+    """kernel="stream" on grids with nx % 4 != 0 (compact rows padded to a multiple of 4, zero pad columns that
+    stay zero because C = 0 there): forward + adjoint + gradient vs the C oracle, 12 steps so that the 2-D
+    case runs the 4-steps-per-launch kernel."""
+    rng = np.random.default_rng(7)
+    nd = len(shape)
+    c = 1500.0 + 1500.0 * rng.random(shape)
+    h, order, npml, nt = 7.5, 8, 4, 12
+    dt = 0.7 * fo.cfl_dt(c.max(), h, nd, order)
+    src = np.array([[s - 1 for s in shape], [s // 2 for s in shape]])   # one source in the last column
+    rec = np.stack([rng.integers(0, s, 9) for s in shape], 1)
+    rec[0] = src[0]
+    w = rng.standard_normal((nt, 2))
+    p = CPropagator(c, h, dt, order, npml)
+    d = p.forward(src, w, rec)
+    r = d + 0.1 * np.abs(d).max() * rng.standard_normal(d.shape)
+    a = p.adjoint(r)
+    o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r, dtype=dtype, kernel="stream")
+    assert o["kernel"].startswith(kern)
+    assert rel(o["seis"], d) < tol and rel(o["adj_src"], a) < tol and rel(o["grad_c"], p.gradient()) < 3 * tol
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json's configs, scaled so the oracle finishes in seconds
 # ---------------------------------------------------------------------------
@@ -231,8 +257,8 @@ def test_error_paths(gpu):
             e.set_model(np.zeros_like(c))  # velocity must be > 0
     with pytest.raises(FwiError):  # the fp64 float4-style kernels exist in 3-D only
         Engine((8, 8), 10.0, 1e-3, 4, dtype="float64", kernel="stream")
-    with pytest.raises(FwiError):  # odd nx cannot be covered by double2 lanes
-        Engine((8, 8, 9), 10.0, 1e-3, 4, dtype="float64", kernel="stream")
+    with Engine((8, 8, 9), 10.0, 1e-3, 4, dtype="float64", kernel="stream") as e:  # any nx (padded compact rows)
+        assert e.kernel_name == "step3d_stream"
 
 
 def test_dot_product_reduction(gpu):
@@ -360,9 +386,11 @@ def test_checkpointed_gradient_equals_store_all(gpu, shape, K):
     assert rel(out[1][3], out[0][3]) < 1e-6
 
 
-def test_device_vector_algebra(gpu):
+@pytest.mark.parametrize("shape", [(20, 17, 24), (20, 17, 23), (21, 30), (9, 5, 1)])
+def test_device_vector_algebra(gpu, shape):
+    """nx % 4 != 0: the device keeps model-shaped arrays with rows padded to a multiple of 4 (zeros in the
+    pad); uploads, downloads, reductions and the clamp must not see the pad."""
     rng = np.random.default_rng(2)
-    shape = (20, 17, 24)
     a, b = rng.standard_normal(shape).astype(np.float32), rng.standard_normal(shape).astype(np.float32)
     with Engine(shape, 10.0, 1e-3, 4) as e:
         e.vec_create(3)
@@ -373,8 +401,10 @@ def test_device_vector_algebra(gpu):
         e.vec_axpby(1, 2.5, 0, -0.5)  # b = 2.5 a - 0.5 b
         assert np.allclose(e.vec_download(1), 2.5 * a - 0.5 * b, rtol=1e-6, atol=1e-6)
         e.vec_copy(2, 0)
-        e.vec_clip(2, -0.25, 0.5)
-        assert np.array_equal(e.vec_download(2), np.clip(a, -0.25, 0.5))
+        e.vec_clip(2, 0.25, 0.5)   # a clamp away from zero: pad columns must stay out of the reductions
+        assert np.array_equal(e.vec_download(2), np.clip(a, 0.25, 0.5))
+        clipped = np.clip(a, 0.25, 0.5).astype(np.float64)
+        assert abs(e.vec_dot(2, 2) - float(np.sum(clipped * clipped))) < 1e-9 * a.size
         with pytest.raises(FwiError):
             e.vec_dot(0, 3)
         # model / gradient hand-over without leaving the device
@@ -382,10 +412,13 @@ def test_device_vector_algebra(gpu):
         e.vec_upload(0, c)
         e.set_model_vec(0)
         wav = fo.ricker(4, 1e-3, 30.0).astype(np.float32)
-        d = e.forward(None, ([[10, 8, 12]], wav), [[3, 3, 3]])
+        pt = [[s // 2 for s in shape]]
+        d = e.forward(None, (pt, wav), [[s // 3 for s in shape]])
         e.adjoint(np.ones_like(d))
         e.gradient_vec(1)
-        assert np.array_equal(e.vec_download(1), e.gradient())
+        g = e.gradient()
+        assert np.all(np.isfinite(g)) and np.array_equal(e.vec_download(1), g)
+        assert abs(e.vec_dot(1, 1) - float(np.sum(g.astype(np.float64) ** 2))) <= 1e-6 * float(np.sum(g.astype(np.float64) ** 2))
 
 
 def test_device_lbfgs_matches_host_lbfgs(gpu):
