@@ -44,8 +44,9 @@ enum { FWI_F32 = 0, FWI_F64 = 1 };
 enum {
     FWI_KERNEL_AUTO = 0,
     FWI_KERNEL_POINT = 1,  /* one thread per grid point, neighbours through L1/L2 */
-    FWI_KERNEL_STREAM = 2  /* fp32 float4 kernels with LDS-staged halo tiles: 3-D z-marching
-                              register queue (step3d_stream) / 2-D row tiles (step2d_tile) */
+    FWI_KERNEL_STREAM = 2  /* 16-byte-per-lane kernels with LDS-staged halo tiles, any grid size: 3-D
+                              z-marching register queue (step3d_stream, fp32 / fp64), 2-D fp32 row
+                              tiles (step2d_tile) and 4-steps-per-launch tiles (step2d_fused) */
 };
 
 enum { FWI_WRT_VELOCITY = 0, FWI_WRT_SLOWNESS2 = 1 };
