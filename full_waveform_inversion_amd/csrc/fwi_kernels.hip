@@ -210,7 +210,10 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
         return;
     }
-    if ((nblk & 7) == 0 && zchunk > 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-contiguous slabs
+    if (zchunk > 0) {  // XCD-contiguous slabs: XCD x runs blocks x, x + 8, ... -> give it one contiguous range
+        const int x = bid & 7, q = nblk >> 3, r = nblk & 7;  // the first r XCDs hold q + 1 blocks
+        bid = x * q + min(x, r) + (bid >> 3);
+    }
     zchunk = abs(zchunk);  // (a negative zchunk is the tuning hook that switches the renumbering off)
     const int bx = bid % nxt;
     const int t2 = bid / nxt;
@@ -221,11 +224,17 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     const int z1 = min(g.nz, z0 + zchunk);
     const bool act = FULL || ((x0 < g.nx) && (y < g.ny));
     const int64_t sz = g.sz, sy = g.sy;
+    // Lanes right of the grid (partial last x tile) own no points and store nothing, but the loop is
+    // branch-free, so they load: all of them read the one all-zero vector just behind the row's last
+    // data vector (pad, never written) -- the same cache line as real data instead of a stream of pad
+    // lines (nx = 384: a third more read traffic before), and exactly the zeros their LDS slots must
+    // show to the neighbouring lanes' x stencil.
+    const int xa = FULL ? x0 : min(x0, ((g.nx - 1) / VL + 1) * VL);
 
     // Addressing: wave-uniform 64-bit plane base (SGPRs) + per-thread 32-bit
     // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
     // same padded layout).
-    const unsigned poff = (unsigned)(g.off0 + (int64_t)y * sy + x0);  // (z = 0, y, x0)
+    const unsigned poff = (unsigned)(g.off0 + (int64_t)y * sy + xa);  // (z = 0, y, x0)
     const unsigned coff = (unsigned)((int64_t)y * g.cx + x0);         // compact, z = 0
     const int64_t cplane = (int64_t)g.ny * g.cx;
 
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         const bool valid = hr < 2 * R;
         const int yh = !valid ? y : (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
         hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
-        hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + x0);
+        hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + xa);
     }
     // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
     // the 4 elements right of it (one scalar load each).
@@ -450,7 +459,8 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     const int z0 = bz * TY, z = z0 + ty;
     const bool act = (x0 < g.nx) && (z < g.nz);
     const int64_t sz = g.sz;
-    const int64_t poff = g.off0 + (int64_t)z * sz + x0;
+    const int xa = min(x0, ((g.nx - 1) / 4 + 1) * 4);  // lanes right of the grid read one shared zero vector
+    const int64_t poff = g.off0 + (int64_t)z * sz + xa;
 
     const f4 ctr = ld4(a.u_cur + poff);
     f4 halo[NH];
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
         const bool valid = hr < 2 * R;
         const int zh = !valid ? z : (hr < R) ? z0 - R + hr : z0 + TY + (hr - R);
         hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
-        halo[i] = ld4(a.u_cur + g.off0 + (int64_t)zh * sz + x0);
+        halo[i] = ld4(a.u_cur + g.off0 + (int64_t)zh * sz + xa);
     }
     const int64_t rowoff = g.off0 + (int64_t)z * sz + bx * TILE_X;
     const int64_t eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
