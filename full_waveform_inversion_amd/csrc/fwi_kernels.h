@@ -69,7 +69,8 @@ struct StreamTuning {
     int ty;      // rows per workgroup (4 or 8)
     int zchunk;  // planes marched per workgroup
     int pf;      // planes fetched ahead of use (1..3)
-    int tile_x;  // x extent of a tile in elements: 64 lanes x one 16-byte vector (256 fp32 / 128 fp64)
+    int tile_x;  // x extent of a tile in elements: at most 64 lanes x one 16-byte vector (256 fp32 /
+                 // 128 fp64); the 3-D kernel takes narrower, equal tiles when nx is not a multiple of that
 };
 
 // Workgroup tile of the stream kernel that owns grid point (z, y, x): the index

@@ -190,7 +190,7 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
 template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
-                                                         int nxt, int nyt, int nblk) {
+                                                         int nxt, int nyt, int nblk, int tw) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
     constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
     constexpr int LROWS = TY + 2 * R + 1;
@@ -218,18 +218,24 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     const int bx = bid % nxt;
     const int t2 = bid / nxt;
     const int by = t2 % nyt, bz = t2 / nyt;
-    const int x0 = bx * TX + VL * lane;
+    // x tiles are `tw` columns wide (a multiple of VL, <= TX): the host splits nx into equal tiles, so
+    // a grid of 384 columns runs as 2 x 192 (48 lanes each) instead of 256 + 128 -- same idle lanes,
+    // but every workgroup then moves the same bytes and none is the straggler (384^3: 224 -> 269
+    // Gpts/s).  FULL: tw == TX.
+    const int twid = FULL ? TX : tw;
+    const int x0 = bx * twid + VL * lane;
     const int y0 = by * TY, y = y0 + ty;
     const int z0 = bz * zchunk;
     const int z1 = min(g.nz, z0 + zchunk);
-    const bool act = FULL || ((x0 < g.nx) && (y < g.ny));
+    const bool act = FULL || ((VL * lane < twid) && (x0 < g.nx) && (y < g.ny));
     const int64_t sz = g.sz, sy = g.sy;
-    // Lanes right of the grid (partial last x tile) own no points and store nothing, but the loop is
-    // branch-free, so they load: all of them read the one all-zero vector just behind the row's last
-    // data vector (pad, never written) -- the same cache line as real data instead of a stream of pad
-    // lines (nx = 384: a third more read traffic before), and exactly the zeros their LDS slots must
-    // show to the neighbouring lanes' x stencil.
-    const int xa = FULL ? x0 : min(x0, ((g.nx - 1) / VL + 1) * VL);
+    // Lanes that own no points store nothing, but the loop is branch-free, so they load.  The first
+    // HALO columns right of the tile are the x halo of its last lanes: those lanes load the real field
+    // there (which makes the right-edge scalars below redundant unless tw == TX).  Lanes further right
+    // repeat the last halo vector, and lanes right of the GRID all read the one all-zero vector just
+    // behind the row's last data vector (pad, never written): the same cache lines as real data instead
+    // of a stream of pad lines, and exactly the zeros the neighbouring lanes' x stencil must see.
+    const int xa = FULL ? x0 : min(min(x0, bx * twid + twid + HALO - VL), ((g.nx - 1) / VL + 1) * VL);
 
     // Addressing: wave-uniform 64-bit plane base (SGPRs) + per-thread 32-bit
     // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     }
     // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
     // the 4 elements right of it (one scalar load each).
-    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * TX);
+    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * twid);
     const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : poff;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
     // idle lanes write consecutive words of the trash row (a 16 B stride would be a 4-way bank conflict)
@@ -584,7 +590,10 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
-    const int tile_x = is_f32 ? 256 : 128;
+    const int full_x = is_f32 ? 256 : 128, vl = is_f32 ? 4 : 2;
+    // 3-D: split nx into equal x tiles (multiples of the lane vector) rather than full ones plus a remainder
+    const int nxt0 = (g.nx + full_x - 1) / full_x;
+    const int tile_x = (g.ndim == 2) ? full_x : (int)round_up((g.nx + nxt0 - 1) / nxt0, vl);
     // 2-D: rows per workgroup.  16 is 7 % faster for a lone shot (6.98 vs 7.46 us/step at 1024^2) but
     // 8 co-schedules better when several shots share the GPU (4 concurrent: 3.5 vs 4.4 us/step/shot).
     if (g.ndim == 2) return StreamTuning{8, 1, 1, tile_x};
@@ -605,9 +614,8 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
 }
 
 template <typename T, int R, int TY, bool DAMP, bool FULL, int PF>
-static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
-    constexpr int TX = 64 * VecOf<T>::VL;
-    const int nxt = stream_nxt(g, TX);
+static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, int zchunk, int tw, hipStream_t s) {
+    const int nxt = stream_nxt(g, tw);
     const int nyt = (g.ny + TY - 1) / TY;
     const int nzc = (g.nz + zchunk - 1) / zchunk;
     const int nblk = nxt * nyt * nzc;
@@ -617,28 +625,28 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
     if (no_remap) zchunk = -zchunk;
     if (a.q_out)
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk);
+                           zchunk, nxt, nyt, nblk, tw);
     else if (a.q_in && a.q_in2)
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk);
+                           zchunk, nxt, nyt, nblk, tw);
     else if (a.q_in)
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk);
+                           zchunk, nxt, nyt, nblk, tw);
     else
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk);
+                           zchunk, nxt, nyt, nblk, tw);
     return hipGetLastError();
 }
 
 template <typename T, int R, int TY, bool DAMP>
-static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<T> &a, int zchunk, hipStream_t s) {
+static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<T> &a, int zchunk, int tw, hipStream_t s) {
     // FULL: every thread of every tile owns grid points, so the stores need no predicate.
     // Prefetch depth: PF = 1 plane ahead measured best (256^3: 39.5 us/step vs 40.0 / 40.2 for
     // PF = 2 / 3; 512^3 equal), i.e. the kernel is throughput- not latency-bound; deeper rings
     // only cost registers.  The template parameter stays for re-tuning.
-    if (g.nx % (64 * VecOf<T>::VL) == 0 && g.ny % TY == 0)
-        return launch_stream_full<T, R, TY, DAMP, true, 1>(g, a, zchunk, s);
-    return launch_stream_full<T, R, TY, DAMP, false, 1>(g, a, zchunk, s);
+    if (g.nx % (64 * VecOf<T>::VL) == 0 && g.ny % TY == 0 && tw == 64 * VecOf<T>::VL)
+        return launch_stream_full<T, R, TY, DAMP, true, 1>(g, a, zchunk, tw, s);
+    return launch_stream_full<T, R, TY, DAMP, false, 1>(g, a, zchunk, tw, s);
 }
 
 template <typename T, int R>
@@ -646,13 +654,13 @@ static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<T> &a, const
     const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
     if (a.damp) {
         switch (t.ty) {
-            case 4: return launch_stream_mode<T, R, 4, true>(g, a, zc, s);
-            default: return launch_stream_mode<T, R, 8, true>(g, a, zc, s);
+            case 4: return launch_stream_mode<T, R, 4, true>(g, a, zc, t.tile_x, s);
+            default: return launch_stream_mode<T, R, 8, true>(g, a, zc, t.tile_x, s);
         }
     }
     switch (t.ty) {
-        case 4: return launch_stream_mode<T, R, 4, false>(g, a, zc, s);
-        default: return launch_stream_mode<T, R, 8, false>(g, a, zc, s);
+        case 4: return launch_stream_mode<T, R, 4, false>(g, a, zc, t.tile_x, s);
+        default: return launch_stream_mode<T, R, 8, false>(g, a, zc, t.tile_x, s);
     }
 }
 
