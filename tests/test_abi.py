@@ -79,3 +79,17 @@ def test_null_context_calls_return_einval():
     assert lib.fwi_gradient(None, 0, None) == 1
     assert lib.fwi_forward(None, 1, 0, None, None, 0, None, 0, None) == 1
     lib.fwi_destroy(None)  # must be a no-op
+
+
+def test_oracle_is_imported_only_by_test_infrastructure():
+    """oracle/ may be used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+    import re
+    offenders = []
+    for base in ("full_waveform_inversion_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".sh")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "oracle/" in text and f.endswith(".sh"):
+                        offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders

@@ -293,7 +293,7 @@ def test_shot_loop_gradient_vs_oracle(gpu):
     """cfg3 scaled: 4 shots, summed misfit and gradient at the smoothed start model.
 
     End to end (observed data is the shared INPUT, each path forms its own residual): the
-    fp32 forward error (~1e-6 of |d|, see tools/parity_report.py) enters the residual
+    fp32 forward error (~1e-6 of |d|, see tests/parity_report.py) enters the residual
     amplified by |d| / |r|, so the bar is scaled by that measured ratio instead of the flat
     1e-5 that holds for the seismograms and for the gradient of a given residual
     (test_baseline_configs_scaled).
