@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -35,7 +35,7 @@ class Config(C.Structure):
                 ("ny", C.c_int32), ("nx", C.c_int32), ("order", C.c_int32), ("nt_max", C.c_int32),
                 ("npml", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
                 ("kernel", C.c_int32), ("zchunk", C.c_int32), ("ckpt_interval", C.c_int32),
-                ("reserved", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
+                ("image_stride", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
                 ("sigma_max", C.c_double)]
 
 

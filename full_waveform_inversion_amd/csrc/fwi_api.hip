@@ -55,6 +55,7 @@ struct fwi_ctx {
     void *c_dev = nullptr;            // compact velocity
     void *dz = nullptr, *dy = nullptr, *dx = nullptr;
     void *q_store = nullptr;  // nt_max x npts forward terms
+    int istride = 1;          // imaging stride: the forward term is stored / correlated every istride-th step
     void *logical = nullptr;  // nz x ny x nx staging array for host <-> compact copies when cx != nx
     void *g_acc = nullptr;    // compact gradient accumulator
     void *g_out = nullptr;    // compact scratch for fwi_gradient
@@ -543,7 +544,8 @@ struct Impl {
     }
 
     static bool use_fused(const fwi_ctx *ctx, int nt) {
-        return ctx->fused2d && nt % FUSED2D_STEPS == 0 && (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
+        return ctx->fused2d && ctx->istride == 1 && nt % FUSED2D_STEPS == 0 &&
+               (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
     }
 
     static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
@@ -613,13 +615,14 @@ struct Impl {
         int rc;
         if ((rc = upload_points(ctx, nsrc, src_idx, nrec, rec_idx))) return rc;
         if (save && K == 0 && !ctx->q_store) {
-            const size_t bytes = (size_t)ctx->cfg.nt_max * g.npts * sizeof(T);
+            const size_t slots = ((size_t)ctx->cfg.nt_max + ctx->istride - 1) / ctx->istride;
+            const size_t bytes = slots * g.npts * sizeof(T);
             size_t fr = 0, tot = 0;
             HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
             if (bytes > fr)
                 return ctx->fail(FWI_ENOMEM,
                                  "forward-term store needs %.1f GiB (nt_max=%d) but only %.1f GiB are free; "
-                                 "set ckpt_interval to trade it for recomputation",
+                                 "set ckpt_interval (recomputation) or image_stride (decimated imaging)",
                                  bytes / 1073741824.0, ctx->cfg.nt_max, fr / 1073741824.0);
             HIPCHK(ctx, hipMalloc(&ctx->q_store, bytes));
         }
@@ -680,7 +683,10 @@ struct Impl {
                                 save ? 1 : 0, q_store)))
                 return rc;
         } else {
-            auto qo = [&](int n) -> T * { return save ? q_store + (size_t)n * g.npts : nullptr; };
+            const int ks = ctx->istride;  // q^n is kept for n % ks == 0, in slot n / ks
+            auto qo = [&](int n) -> T * {
+                return (save && n % ks == 0) ? q_store + (size_t)(n / ks) * g.npts : nullptr;
+            };
             if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, noq)))
                 return rc;
         }
@@ -736,8 +742,8 @@ struct Impl {
                     pq[hi - n] = mine;
                     pq2[hi - n] = pending;
                     pending = nullptr;
-                } else if (mine && n > lo) {
-                    pending = mine;  // first step of a pair: defer
+                } else if (mine && n > lo && ctx->istride == 1) {
+                    pending = mine;  // first step of a pair: defer (every step images: the next one pairs)
                 } else {
                     pq[hi - n] = mine;  // single (last step of an odd run, or nothing to pair)
                 }
@@ -813,8 +819,10 @@ struct Impl {
             }
             q0 = carry;
         } else {
+            const int ks = ctx->istride;
             plan(nt - 1, 0, [&](int n) -> const T * {
-                return (image && n + 1 < nt) ? q_store + (size_t)(n + 1) * g.npts : nullptr;
+                return (image && n + 1 < nt && (n + 1) % ks == 0) ? q_store + (size_t)((n + 1) / ks) * g.npts
+                                                                   : nullptr;
             });
             auto qi = [&](int n, const T *&p, const T *&p2) { p = pq[nt - 1 - n]; p2 = pq2[nt - 1 - n]; };
             if ((rc = run_steps(ctx, sw, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, none, qi))) return rc;
@@ -836,7 +844,7 @@ struct Impl {
     }
 
     static int gradient_vec(fwi_ctx *ctx, int32_t wrt, void *dev) {
-        const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
+        const double scale = -(double)ctx->istride / (ctx->cfg.dt * ctx->cfg.dt);  // istride: quadrature weight
         HIPCHK(ctx, launch_finalize_gradient<T>(ctx->gd, (const T *)ctx->g_acc, (const T *)ctx->c_dev, (T *)dev, scale,
                                                 wrt == FWI_WRT_VELOCITY, ctx->stream));
         return FWI_OK;
@@ -870,7 +878,7 @@ struct Impl {
 
     static int gradient(fwi_ctx *ctx, int32_t wrt, T *out) {
         const GridDesc &g = ctx->gd;
-        const double scale = -1.0 / (ctx->cfg.dt * ctx->cfg.dt);
+        const double scale = -(double)ctx->istride / (ctx->cfg.dt * ctx->cfg.dt);  // istride: quadrature weight
         HIPCHK(ctx, launch_finalize_gradient<T>(g, (const T *)ctx->g_acc, (const T *)ctx->c_dev,
                                                 (T *)ctx->g_out, scale, wrt == FWI_WRT_VELOCITY, ctx->stream));
         int rc = download_compact(ctx, out, ctx->g_out);
@@ -985,6 +993,9 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->npml > 0 && !(cfg->sigma_max >= 0)) return bad("sigma_max must be >= 0 when npml > 0");
     if (cfg->kernel < FWI_KERNEL_AUTO || cfg->kernel > FWI_KERNEL_STREAM) return bad("unknown kernel id");
     if (cfg->ckpt_interval < 0) return bad("ckpt_interval must be >= 0");
+    if (cfg->image_stride < 0) return bad("image_stride must be >= 0");
+    if (cfg->image_stride > 1 && cfg->ckpt_interval > 0)
+        return bad("image_stride > 1 and ckpt_interval > 0 cannot be combined");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
@@ -1001,6 +1012,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->gd = make_grid(cfg->ndim, cfg->nz, cfg->ny, cfg->nx, cfg->order);
     ctx->esize = cfg->dtype == FWI_F32 ? 4 : 8;
     ctx->ckpt = cfg->ckpt_interval;
+    ctx->istride = cfg->image_stride > 1 ? cfg->image_stride : 1;
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;

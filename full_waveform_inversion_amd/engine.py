@@ -40,10 +40,13 @@ class Engine:
     ``forward``; ``gradient`` returns the sum over all adjoint calls since
     ``reset_gradient``.  ``ckpt_interval = K > 0`` replaces the store of every step's imaging term
     (``nt_max`` model-sized arrays) by wavefield snapshots every K steps plus recomputation.
+    ``image_stride = S > 1`` stores and correlates the imaging term every S-th step only (weight S): an
+    approximation of the time integral that is accurate while ``S * dt`` still samples the wavelet's
+    band, with a store S times smaller and less adjoint traffic.
     """
 
     def __init__(self, shape, h, dt, nt_max, order=8, npml=0, sigma_max=None, dtype="float32",
-                 device=0, kernel="auto", zchunk=0, ckpt_interval=0):
+                 device=0, kernel="auto", zchunk=0, ckpt_interval=0, image_stride=1):
         shape = tuple(int(s) for s in shape)
         if len(shape) not in (2, 3):
             raise ValueError("shape must be (nz, nx) or (nz, ny, nx)")
@@ -59,6 +62,7 @@ class Engine:
                         "stream": _lib.KERNEL_STREAM}[kernel]
         self._zchunk = int(zchunk)
         self._ckpt = int(ckpt_interval)
+        self._istride = int(image_stride)
         self._lib = _lib.load()
         self._ctx = None
         self._nsrc = self._nrec = self._nt = 0
@@ -74,7 +78,7 @@ class Engine:
         cfg = _lib.Config(C.sizeof(_lib.Config), self.ndim, nz, ny, nx, self.order, self.nt_max,
                           self.npml, self.device,
                           _lib.F32 if self.dtype == np.float32 else _lib.F64, self._kernel,
-                          self._zchunk, self._ckpt, 0, self.h, self.dt, float(self.sigma_max))
+                          self._zchunk, self._ckpt, self._istride, self.h, self.dt, float(self.sigma_max))
         ctx = C.c_void_p()
         _lib.check(None, self._lib.fwi_create(C.byref(cfg), C.byref(ctx)))
         self._ctx = ctx

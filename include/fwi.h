@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 6
+#define FWI_ABI_VERSION 7
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -77,7 +77,12 @@ typedef struct fwi_config {
                               K > 0: snapshot the wavefields every K steps and recompute each
                               K-step forward segment during fwi_adjoint (one extra forward sweep,
                               ~(2 nt_max / K + K) x npts elements)  [SURVEY s.8f-3] */
-    int32_t reserved;    /* keep 0 */
+    int32_t image_stride; /* 0 / 1: the imaging condition uses every time step (the exact discrete
+                              gradient).  S > 1: the forward term is stored and correlated every S-th
+                              step only, weighted by S (a Riemann sum over the oversampled time axis):
+                              the store shrinks to ceil(nt_max / S) x npts elements and the adjoint
+                              sweep skips the imaging traffic on the other steps.  Not combinable with
+                              ckpt_interval; 2-D grids then run one step per launch. */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the sponge, >= 0 (used when npml > 0) */

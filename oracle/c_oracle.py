@@ -66,7 +66,8 @@ def _ip(a):
 class CPropagator:
     """fp64 forward/adjoint/gradient through the C oracle."""
 
-    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, threads=None):
+    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, threads=None, image_stride=1):
+        self.image_stride = max(1, int(image_stride))  # see Propagator: imaging every S-th step, weight S
         self.c = np.ascontiguousarray(c, np.float64)
         self.shape = self.c.shape
         self.ndim = self.c.ndim
@@ -103,8 +104,16 @@ class CPropagator:
     def adjoint(self, residual, image=True):
         r = np.ascontiguousarray(residual, np.float64)
         self._img = np.zeros(self.shape) if image else None
-        return self._run(True, self.rec_flat, r, 1.0, self.src_flat, 1.0 / self.h ** self.ndim,
-                         False, self._img)
+        S = self.image_stride
+        if image and S > 1:  # the C loop correlates every step: blank the terms the stride skips
+            keep = np.zeros(self.nt, bool)
+            keep[::S] = True
+            self.q_store[~keep] = 0.0
+        out = self._run(True, self.rec_flat, r, 1.0, self.src_flat, 1.0 / self.h ** self.ndim,
+                        False, self._img)
+        if image and S > 1:
+            self._img *= S
+        return out
 
     def gradient(self, wrt="velocity"):
         g_m = -self._img / self.dt ** 2

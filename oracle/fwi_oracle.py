@@ -96,8 +96,11 @@ def _ravel_idx(idx, shape):
 class Propagator:
     """fp64 (or any ``dtype``) restatement of one shot's forward/adjoint/gradient."""
 
-    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, dtype=np.float64):
+    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, dtype=np.float64, image_stride=1):
         c = np.asarray(c, dtype=np.float64)
+        # image_stride S > 1: the imaging condition is a Riemann sum over every S-th step,
+        # img = S * sum_{n % S == 0} mu^{n+1} q^n  (the engine's fwi_config.image_stride)
+        self.image_stride = max(1, int(image_stride))
         if c.ndim not in (2, 3):
             raise ValueError("model must be 2-D (nz,nx) or 3-D (nz,ny,nx)")
         if order not in COEFFS:
@@ -164,8 +167,8 @@ class Propagator:
             u_next = self.A * (2 * u_cur - self.B * u_prev + q)
             if save_q:
                 qs[n] = q
-            if img is not None:
-                img += u_next.astype(np.float64) * image_q[n]
+            if img is not None and n % self.image_stride == 0:
+                img += self.image_stride * (u_next.astype(np.float64) * image_q[n])
             rec[n] = u_next.reshape(-1)[rec_flat] * dt_.type(rec_scale)
             u_prev, u_cur = u_cur, u_next
         self._last = (u_prev, u_cur)

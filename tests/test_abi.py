@@ -49,11 +49,12 @@ def test_create_rejects_bad_configs_before_touching_the_gpu():
     lib = _lib.load()
     ctx = C.c_void_p()
     good = dict(struct_size=C.sizeof(_lib.Config), ndim=3, nz=8, ny=8, nx=8, order=8, nt_max=4, npml=0,
-                device=0, dtype=_lib.F32, kernel=_lib.KERNEL_AUTO, zchunk=0, ckpt_interval=0, reserved=0, h=10.0,
+                device=0, dtype=_lib.F32, kernel=_lib.KERNEL_AUTO, zchunk=0, ckpt_interval=0, image_stride=0, h=10.0,
                 dt=1e-3,
                 sigma_max=0.0)
     for bad in (dict(ndim=4), dict(order=6), dict(nz=0), dict(nt_max=0), dict(h=0.0), dict(dt=-1.0),
-                dict(dtype=7), dict(struct_size=8), dict(npml=-1), dict(kernel=9), dict(ckpt_interval=-1)):
+                dict(dtype=7), dict(struct_size=8), dict(npml=-1), dict(kernel=9), dict(ckpt_interval=-1), dict(image_stride=-1),
+                dict(image_stride=4, ckpt_interval=8)):
         cfg = _lib.Config(**{**good, **bad})
         rc = lib.fwi_create(C.byref(cfg), C.byref(ctx))
         assert rc == 1, bad  # FWI_EINVAL

@@ -421,6 +421,52 @@ def test_device_vector_algebra(gpu, shape):
         assert abs(e.vec_dot(1, 1) - float(np.sum(g.astype(np.float64) ** 2))) <= 1e-6 * float(np.sum(g.astype(np.float64) ** 2))
 
 
+@pytest.mark.parametrize("shape,dtype,tol", [((24, 20, 32), "float32", TOL32), ((24, 20, 31), "float64", TOL64),
+                                             ((48, 64), "float32", TOL32)])
+@pytest.mark.parametrize("stride", [2, 3, 7])
+def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, stride):
+    """fwi_config.image_stride: the forward term is stored / correlated every S-th step with weight S -- same
+    gradient as the oracle with the same stride, for nt not a multiple of S, two shots accumulated."""
+    rng = np.random.default_rng(11)
+    nd = len(shape)
+    c = 1800.0 + 900.0 * rng.random(shape)
+    h, order, npml, nt = 8.0, 8, 4, 41
+    dt = 0.6 * fo.cfl_dt(c.max(), h, nd, order)
+    rec = np.stack([rng.integers(0, s, 7) for s in shape], 1)
+    p = CPropagator(c, h, dt, order, npml, image_stride=stride)
+    g_ref = np.zeros(shape)
+    with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, dtype=dtype,
+                image_stride=stride) as e:
+        for shot in range(2):
+            src = np.stack([rng.integers(0, s, 2) for s in shape], 1)
+            w = rng.standard_normal((nt, 2))
+            d = p.forward(src, w, rec)
+            r = d + 0.2 * np.abs(d).max() * rng.standard_normal(d.shape)
+            a = p.adjoint(r)
+            g_ref += p.gradient()
+            dg = e.forward(c, (src, w), rec, save=True)
+            ag = e.adjoint(r)
+            assert rel(dg, d) < tol and rel(ag, a) < tol
+        assert rel(e.gradient(), g_ref) < 3 * tol
+        assert not e.kernel_name.startswith("step_point")
+
+
+def test_image_stride_shrinks_the_store(gpu):
+    """A store-all run that does not fit is refused; the same run with a stride allocates 1/S of it."""
+    shape, nt = (256, 256, 256), 6000   # 6000 x 64 MiB = 375 GiB > 288 GB
+    with Engine(shape, 10.0, 1e-3, nt) as e:
+        e.set_model(np.full(shape, 2000.0, np.float32))
+        with pytest.raises(FwiError) as ei:
+            e.forward(None, ([[128, 128, 128]], np.zeros(8, np.float32)), [[8, 8, 8]], save=True)
+        assert ei.value.code == 4 and "image_stride" in str(ei.value)
+    with Engine(shape, 10.0, 1e-3, nt, image_stride=8) as e:   # 750 slots = 47 GiB
+        e.set_model(np.full(shape, 2000.0, np.float32))
+        w = fo.ricker(16, 1e-3, 30.0).astype(np.float32)
+        d = e.forward(None, ([[128, 128, 128]], w), [[120, 128, 128]], save=True)
+        e.adjoint(np.ones_like(d))
+        assert np.isfinite(e.gradient()).all()
+
+
 def test_device_lbfgs_matches_host_lbfgs(gpu):
     """Same iterates from the device-resident and the host L-BFGS on a small 3-D inversion."""
     from full_waveform_inversion_amd import shots as sh

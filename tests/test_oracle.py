@@ -157,6 +157,34 @@ def test_c_oracle_matches_numpy_oracle(shape, order):
     assert rel(q.gradient(), p.gradient()) < 1e-12
 
 
+@pytest.mark.parametrize("stride", [2, 3, 5])
+def test_image_stride_definition_and_accuracy(stride):
+    """image_stride S: img = S * sum_{n % S == 0} mu^{n+1} q^n.  Both oracles agree on it, and for a wavelet
+    that S * dt still samples well it approximates the exact discrete gradient."""
+    n, order, npml = 40, 8, 4
+    c = np.full((n, n), 2000.0)
+    c[n // 2:, :] = 2600.0
+    h = 10.0
+    dt = 0.5 * fo.cfl_dt(c.max(), h, 2, order)   # f0 = 12 Hz, dt ~ 1.2 ms: >= 35 samples per period
+    nt = 180
+    w = fo.ricker(nt, dt, 12.0)
+    src, rec = [[6, 20]], [[6, x] for x in range(4, 36, 4)]
+    full = fo.Propagator(c, h, dt, order, npml)
+    d = full.forward(src, w, rec)
+    r = 0.3 * d
+    full.adjoint(r)
+    g_full = full.gradient()
+    ps = fo.Propagator(c, h, dt, order, npml, image_stride=stride)
+    cs = CPropagator(c, h, dt, order, npml, image_stride=stride)
+    for p in (ps, cs):
+        p.forward(src, w, rec)
+        p.adjoint(r)
+    g_s = ps.gradient()
+    assert rel(cs.gradient(), g_s) < 1e-12
+    assert rel(g_s, g_full) < 0.02 * stride   # quadrature error of the Riemann sum, small while oversampled
+    assert rel(g_s, g_full) > 1e-9            # ... but it IS a different (decimated) sum
+
+
 def test_empty_point_sets():
     """No sources -> zero data; no receivers -> (nt, 0) output; both oracles agree."""
     c = np.full((20, 20), 2000.0)
