@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--npml", type=int, default=0)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--zchunk", type=int, default=0)
+    ap.add_argument("--image-stride", type=int, default=1,
+                    help="gradient mode: store / correlate the forward term every S-th step (fwi_config.image_stride)")
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
                     help="forward: the headline stencil run; gradient: forward(save) + adjoint(imaging) per step")
     ap.add_argument("--single-device", action="store_true",
@@ -104,7 +106,7 @@ def main():
     wav = w.wavelet()
     model = w.c.astype(np.float32)
     e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local, kernel=args.kernel,
-               zchunk=args.zchunk)
+               zchunk=args.zchunk, image_stride=args.image_stride)
     t_sm = time.perf_counter()
     e.set_model(model)
     set_model_ms = 1e3 * (time.perf_counter() - t_sm)  # host padding + H2D, once per model (not timed)
@@ -192,7 +194,11 @@ def main():
         npts = int(np.prod(w.shape))
         sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
         # forward+save 20 B; adjoint + paired imaging 24 B (SURVEY s.8d prices the unpaired form at 28 B)
-        bpu = (20 + 24) / 2.0 if grad else BYTES_PER_UPDATE
+        S = max(1, args.image_stride)
+        if grad and S > 1:  # every S-th step stores q (+4 B) / reads q and read-modify-writes g (+12 B)
+            bpu = ((16 + 4.0 / S) + (16 + 12.0 / S)) / 2.0
+        else:
+            bpu = (20 + 24) / 2.0 if grad else BYTES_PER_UPDATE
         updates = npts * w.nt * sweeps
         value = world * args.steps * updates / el / 1e9
         kern_us = 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps)  # avg launch-to-launch time per step kernel
@@ -207,7 +213,7 @@ def main():
             "data": "synthetic", "set_model_ms": round(set_model_ms, 1),
             "config": {"workload": "configs[3]: 3-D %s constant velocity, 1 shot/GPU/step, %d time steps, "
                                    "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
-                       "kernel": e.kernel_name, "parallelism": "shot-parallel x%d" % world,
+                       "kernel": e.kernel_name, "image_stride": S, "parallelism": "shot-parallel x%d" % world,
                        "exchange": exchange},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
