@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--host-lbfgs", action="store_true", help="keep the optimiser vectors on the host")
     ap.add_argument("--pool", type=int, default=0,
                     help="engines sharing this GPU's shots concurrently; 0 = auto (2 in 2-D, 1 in 3-D)")
+    ap.add_argument("--image-stride", type=int, default=1,
+                    help="imaging condition every S-th step (fwi_config.image_stride)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -39,7 +41,7 @@ def main():
     from full_waveform_inversion_amd import default_sigma_max
     sigma = default_sigma_max(float(w.c.max()), w.h, w.npml)
     pool = sh.EnginePool(lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
-                                        sigma_max=sigma), psize)
+                                        sigma_max=sigma, image_stride=a.image_stride), psize)
     e = pool.primary
     ex = sh.NoExchange()
     dist = None
