@@ -501,6 +501,7 @@ struct Impl {
                 a.damp = b.damp;
                 a.mode = mode;
                 a.q_base = (float *)q_base;
+                a.istride = ctx->istride;
                 a.g = (float *)ctx->g_acc;
                 a.n0 = n0 + done * dn;
                 a.dn = dn;
@@ -544,8 +545,7 @@ struct Impl {
     }
 
     static bool use_fused(const fwi_ctx *ctx, int nt) {
-        return ctx->fused2d && ctx->istride == 1 && nt % FUSED2D_STEPS == 0 &&
-               (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
+        return ctx->fused2d && nt % FUSED2D_STEPS == 0 && (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
     }
 
     static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,

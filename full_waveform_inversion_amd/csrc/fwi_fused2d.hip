@@ -116,6 +116,9 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
 
     for (int s = 0; s < KS; ++s) {
         const int n = a.n0 + s * a.dn;  // global time-step index of this sub-step
+        // imaging stride: q^n is stored / correlated for n % istride == 0 only, in slot n / istride
+        const bool qstep = (SAVE_Q || IMAGE) && (a.istride <= 1 || n % a.istride == 0);
+        float *const qslot = a.q_base + (int64_t)(a.istride <= 1 ? n : n / a.istride) * g.npts;
         // Only the rows that must still be exact after this sub-step are updated: the exact region
         // shrinks by R per sub-step towards the interior (trapezoid).  Rows only: the test is (nearly)
         // wave-uniform; also cutting columns diverges lanes and measured slower (4.8 vs 4.1 us/step).
@@ -129,9 +132,9 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 const int lz = gi / E4, l4 = gi % E4;
                 const bool interior = gi < NG && lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
                 qv[i] = nt4{0.f, 0.f, 0.f, 0.f};
-                if (interior && inside[i] == 0xF)
+                if (qstep && interior && inside[i] == 0xF)
                     qv[i] = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(
-                        a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4)));
+                        qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4)));
             }
         }
         // ---- stencil update ---------------------------------------------------------------------------
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 if (!((inside[i] >> j) & 1u)) un.v[j] = 0.f;  // Dirichlet: zero outside the grid
             }
             prv[lz][l4] = un;  // in place: only this thread reads prv[lz][l4]
-            if (SAVE_Q) {
+            if (SAVE_Q && qstep) {
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
                 if (interior && inside[i]) {
-                    float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
+                    float *qp = qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
                     if (inside[i] == 0xF) {
                         nt4 v = {q.v[0], q.v[1], q.v[2], q.v[3]};
                         __builtin_nontemporal_store(v, reinterpret_cast<nt4 *>(qp));
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 const float amp = a.inj_amp[(int64_t)n * a.ninj + a.inj_col[i]];
                 const int lz = a.inj_lz[i], lx = a.inj_lx[i];
                 atomicAdd(&prv[lz][lx >> 2].v[lx & 3], a.inj_cu[i] * amp);
-                if (SAVE_Q && a.inj_interior[i])
-                    atomicAdd(a.q_base + (int64_t)n * g.npts + a.inj_cidx[i], a.inj_cq[i] * amp);
+                if (SAVE_Q && qstep && a.inj_interior[i])
+                    atomicAdd(qslot + a.inj_cidx[i], a.inj_cq[i] * amp);
             }
             __syncthreads();
         }
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
             a.rec_out[(int64_t)n * a.nrec + a.rec_col[i]] = prv[lz][lx >> 2].v[lx & 3] * a.rec_scale;
         }
         // ---- imaging: g += mu^{n+1} * q^n on the interior ---------------------------------------------
-        if (IMAGE) {
+        if (IMAGE && qstep) {
 #pragma unroll
             for (int i = 0; i < GPT; ++i) {
                 const int gi = tid + i * FNT;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                 const int lz = gi / E4, l4 = gi % E4;
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
                 if (interior && inside[i]) {
-                    const float *qp = a.q_base + (int64_t)n * g.npts + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
+                    const float *qp = qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
                     const q4 u = prv[lz][l4];
                     if (inside[i] == 0xF) {
 #pragma unroll

@@ -121,7 +121,8 @@ struct Fused2dArgs {
     float ck[5];
     int damp;
     int mode;                          // 0 plain, 1 store q (SAVE_Q), 2 imaging against stored q (IMAGE)
-    float *q_base;                     // q of step n lives at q_base + n * npts (compact)
+    float *q_base;                     // q of step n lives at q_base + n * npts (compact) ...
+    int istride;                       // ... or, with istride > 1, for n % istride == 0 only, at slot n / istride
     float *g;                          // compact gradient accumulator (mode 2)
     int n0, dn;                        // first step index of the launch and +1 / -1
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region

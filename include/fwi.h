@@ -82,7 +82,7 @@ typedef struct fwi_config {
                               step only, weighted by S (a Riemann sum over the oversampled time axis):
                               the store shrinks to ceil(nt_max / S) x npts elements and the adjoint
                               sweep skips the imaging traffic on the other steps.  Not combinable with
-                              ckpt_interval; 2-D grids then run one step per launch. */
+                              ckpt_interval. */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the sponge, >= 0 (used when npml > 0) */

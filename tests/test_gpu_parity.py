@@ -421,16 +421,17 @@ def test_device_vector_algebra(gpu, shape):
         assert abs(e.vec_dot(1, 1) - float(np.sum(g.astype(np.float64) ** 2))) <= 1e-6 * float(np.sum(g.astype(np.float64) ** 2))
 
 
-@pytest.mark.parametrize("shape,dtype,tol", [((24, 20, 32), "float32", TOL32), ((24, 20, 31), "float64", TOL64),
-                                             ((48, 64), "float32", TOL32)])
+@pytest.mark.parametrize("shape,dtype,tol,nt", [((24, 20, 32), "float32", TOL32, 41), ((24, 20, 31), "float64", TOL64, 41),
+                                                ((48, 64), "float32", TOL32, 41),    # 2-D, one step per launch
+                                                ((70, 131), "float32", TOL32, 40)])  # 2-D, 4 steps per launch
 @pytest.mark.parametrize("stride", [2, 3, 7])
-def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, stride):
+def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, nt, stride):
     """fwi_config.image_stride: the forward term is stored / correlated every S-th step with weight S -- same
     gradient as the oracle with the same stride, for nt not a multiple of S, two shots accumulated."""
     rng = np.random.default_rng(11)
     nd = len(shape)
     c = 1800.0 + 900.0 * rng.random(shape)
-    h, order, npml, nt = 8.0, 8, 4, 41
+    h, order, npml = 8.0, 8, 4
     dt = 0.6 * fo.cfl_dt(c.max(), h, nd, order)
     rec = np.stack([rng.integers(0, s, 7) for s in shape], 1)
     p = CPropagator(c, h, dt, order, npml, image_stride=stride)
@@ -448,7 +449,7 @@ def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, stri
             ag = e.adjoint(r)
             assert rel(dg, d) < tol and rel(ag, a) < tol
         assert rel(e.gradient(), g_ref) < 3 * tol
-        assert not e.kernel_name.startswith("step_point")
+        assert e.kernel_name == ("step3d_stream" if nd == 3 else "step2d_fused")
 
 
 def test_image_stride_shrinks_the_store(gpu):
