@@ -400,7 +400,7 @@ struct Impl {
             // entries of the fused 2-D kernel: a point is injected by every tile whose EXTENDED region
             // holds it (each keeps a private copy of the halo) and sampled by the one tile owning it
             constexpr int FT = FUSED2D_TILE;
-            const int HL = FUSED2D_STEPS * g.r;
+            const int HL = (FUSED2D_STEPS * g.r + 3) / 4 * 4;  // as in step2d_fused
             const int ntx = (g.nx + FT - 1) / FT, ntz = (g.nz + FT - 1) / FT, ntile = ntx * ntz;
             struct Ent { int tile, lz, lx, col; unsigned char interior; };
             std::vector<Ent> ents;

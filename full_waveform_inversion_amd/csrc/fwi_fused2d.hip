@@ -43,7 +43,7 @@ __device__ __forceinline__ float rcp1(float a) {
 template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE>
 __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
     constexpr int FNT = IMAGE ? 512 : 1024;
-    constexpr int HL = KS * R;           // halo cells per side
+    constexpr int HL = (KS * R + 3) / 4 * 4;  // halo cells per side (float4 aligned)
     constexpr int E = FT + 2 * HL;       // extended tile edge (rows and columns)
     constexpr int E4 = E / 4;            // float4 groups per row
     constexpr int NG = E * E4;           // groups in the extended tile
