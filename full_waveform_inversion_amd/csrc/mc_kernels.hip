@@ -46,9 +46,14 @@ struct SeqMom {  // moments of a pair of (possibly upsampled) sequences of commo
 __device__ __forceinline__ double corr_from(const SeqMom &m) {  // Pearson r == the reference's CC
     const double mx = m.sx / m.len, my = m.sy / m.len;
     const double cov = m.sxy / m.len - mx * my;
-    const double vx = m.sxx / m.len - mx * mx, vy = m.syy / m.len - my * my;
+    const double ex2 = m.sxx / m.len, ey2 = m.syy / m.len;
+    const double vx = ex2 - mx * mx, vy = ey2 - my * my;
+    // A constant sequence (one-sample traces, flat data): the reference's centred sums give exactly 0 and
+    // 0/0 = NaN; from raw moments the variance is round-off of either sign instead.  Anything below
+    // 1e-13 of the mean square carries no information in double precision: report it like the reference.
+    if (!(vx > 1e-13 * ex2) || !(vy > 1e-13 * ey2)) return NAN;
     const double r = cov / (sqrt(vx) * sqrt(vy));
-    return r < 0.0 ? 0.0 : r;  // NaN (zero variance) propagates like in the reference
+    return r < 0.0 ? 0.0 : r;
 }
 
 // sums of the 4x interpolated sequence built from a plain sequence described by its moments

@@ -1,0 +1,39 @@
+"""Wide seeded fuzz of the Monte Carlo scoring kernels against the pinned oracle (a script, not collected by
+pytest): `python tests/fuzz_mc.py SEED COUNT` on a GPU box.  Random trace counts, component counts (3 / 6 / 9 take the
+lane-per-sample kernel, anything else the moment kernel), trace lengths from 1, ragged sample counts, all metrics and
+dispatcher modes."""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from full_waveform_inversion_amd import source_inversion as si  # noqa: E402
+from oracle import mc_oracle as mo  # noqa: E402
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
+    k = int(rng.integers(1, 31))
+    n = int(rng.choice([3, 6, 9, int(rng.integers(1, 11))]))
+    t = int(rng.choice([1, 2, 3, 4, 5, int(rng.integers(6, 80))]))
+    N = int(rng.choice([1, 2, 63, 64, 255, 256, 257, int(rng.integers(1, 700))]))
+    metric = str(rng.choice(["VR", "CC", "PCC", "CC-shift", "gau"]))
+    norm, allat = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    G = rng.standard_normal((k, n, t)) * 10.0 ** rng.integers(-3, 4)
+    Ms = rng.standard_normal((n, N))
+    d = np.einsum("kjt,j->kt", G, Ms[:, rng.integers(0, N)]) + 0.2 * np.abs(G).mean() * rng.standard_normal((k, t))
+    nref = min(N, 8 if metric == "CC-shift" else 60)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = mo.score_samples(G, d, Ms[:, :nref], metric, norm, allat)[0]
+    sim, like, post = si.score_samples(d, G, Ms, metric, norm, allat)
+    ok = np.allclose(sim[:nref], ref, rtol=1e-8, atol=1e-10, equal_nan=True)
+    okl = np.allclose(like, np.exp(-(1.0 - sim) / 2.0), rtol=1e-12, atol=0, equal_nan=True)
+    if not (ok and okl and sim.shape == (N,)):
+        bad += 1
+        mism = ~np.isclose(sim[:nref], ref, rtol=1e-8, atol=1e-10, equal_nan=True)
+        print("FAIL", case, (k, n, t, N), metric, norm, allat, "gpu", sim[:nref][mism][:4], "ref", ref[mism][:4],
+              "like ok", okl, flush=True)
+print("done, failures:", bad)
