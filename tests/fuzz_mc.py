@@ -36,4 +36,23 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
         mism = ~np.isclose(sim[:nref], ref, rtol=1e-8, atol=1e-10, equal_nan=True)
         print("FAIL", case, (k, n, t, N), metric, norm, allat, "gpu", sim[:nref][mism][:4], "ref", ref[mism][:4],
               "like ok", okl, flush=True)
+# device sampler: random types / seeds / index ranges against the oracle's generator + the reference maps
+from full_waveform_inversion_amd import samplers  # noqa: E402
+for case in range(60):
+    typ = str(rng.choice(samplers.INVERSION_TYPES))
+    seed = int(rng.integers(0, 2 ** 63))
+    first = int(rng.choice([0, 1, 2 ** 32 - 3, 2 ** 40 + 17, int(rng.integers(0, 2 ** 50))]))
+    N = int(rng.choice([1, 64, 257, int(rng.integers(1, 900))]))
+    amp = float(10.0 ** rng.integers(-3, 4))
+    M, frac = si.sample_on_device(typ, N, seed, first, amp)
+    with np.errstate(all="ignore"):
+        Mr, fr = samplers.from_deviates(typ, mo.device_sampler_deviates(typ, seed, first, N))
+    good = np.isfinite(Mr).all(axis=0)
+    ok = np.array_equal(good, np.isfinite(M).all(axis=0)) and np.allclose(M[:, good], amp * Mr[:, good], rtol=0,
+                                                                          atol=2e-11 * amp)
+    if fr is not None:
+        ok = ok and np.allclose(frac, fr, rtol=0, atol=1e-15)
+    if not ok:
+        bad += 1
+        print("FAIL sampler", typ, seed, first, N, amp, flush=True)
 print("done, failures:", bad)
