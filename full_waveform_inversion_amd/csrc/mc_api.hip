@@ -76,7 +76,7 @@ int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
         gerr = "fwi_mc_score: bad metric or null output";
         return FWI_EINVAL;
     }
-    const bool lane_kernel = n == 3 || n == 6 || n == 9;  // keeps everything in registers: no limit on k
+    const bool lane_kernel = n <= 9;  // keeps everything in registers: no limit on k
     if (!lane_kernel && fwi::mc_score_lds_bytes(k, n) > 64 * 1024) {
         gerr = std::string(fn) + ": k * n too large for the moment kernel's per-workgroup table";
         return FWI_EINVAL;
@@ -113,7 +113,7 @@ int mc_score_impl(const char *fn, int32_t device, int32_t k, int32_t n, int32_t 
     const size_t mc_pad = 1024;  // bytes of zero padding behind Gt and d (>= 2 pipelined groups of 9 doubles)
     const size_t gb = (size_t)k * n * t * 8, db = (size_t)k * t * 8, mb = (size_t)n * nsamp * 8, sb = (size_t)nsamp * 8;
     MCCHK(hipMalloc(&G.p, gb));
-    if (n == 3 || n == 6 || n == 9) {  // packed [k][t][n + 1] stream for the lane-per-sample kernel's scalar loads
+    if (lane_kernel) {  // packed [k][t][n + 1] stream for the lane-per-sample kernel's scalar loads
         const size_t row = (size_t)n + 1, pb = (size_t)k * t * row * 8;
         std::vector<double> gt((size_t)k * t * row);
         for (int kk = 0; kk < k; ++kk)

@@ -279,8 +279,36 @@ typedef double sd8 __attribute__((ext_vector_type(8)));
 typedef double sd4 __attribute__((ext_vector_type(4)));
 typedef double sd2 __attribute__((ext_vector_type(2)));
 constexpr int MC_LANES_UNROLL = 2;  // rows per group; the stream carries >= 3 groups of zero padding
+// Generic stage: 2 (NC + 1) doubles cut into pieces of 8 / 8 / 4 / 2 (NC = 3, 6, 9 -- the counts the
+// reference produces -- have hand-written single-asm forms below).
 template <int NC>
-struct McStage;
+struct McStage {
+    static constexpr int D = 2 * (NC + 1), N8 = D / 8, H4 = (D % 8) / 4, H2 = (D % 4) / 2;
+    sd8 a, b;
+    sd4 c;
+    sd2 e;
+    __device__ __forceinline__ void load(const double *p, double &pin) {
+        if constexpr (N8 >= 1) asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=&s"(a), "+v"(pin) : "s"(p) : "memory");
+        if constexpr (N8 >= 2) asm volatile("s_load_dwordx16 %0, %2, 0x40" : "=&s"(b), "+v"(pin) : "s"(p) : "memory");
+        if constexpr (H4 == 1)
+            asm volatile("s_load_dwordx8 %0, %2, %3" : "=&s"(c), "+v"(pin) : "s"(p), "n"(64 * N8) : "memory");
+        if constexpr (H2 == 1)
+            asm volatile("s_load_dwordx4 %0, %2, %3" : "=&s"(e), "+v"(pin) : "s"(p), "n"(64 * N8 + 32 * H4) : "memory");
+    }
+    __device__ __forceinline__ void fence() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (N8 >= 1) asm volatile("" : "+s"(a));  // every later use of a piece depends on these,
+        if constexpr (N8 >= 2) asm volatile("" : "+s"(b));  // and volatile asms keep their order
+        if constexpr (H4 == 1) asm volatile("" : "+s"(c));
+        if constexpr (H2 == 1) asm volatile("" : "+s"(e));
+    }
+    __device__ __forceinline__ double at(int i) const {
+        if (i < 8 * N8) return i < 8 ? a[i & 7] : b[i & 7];
+        i -= 8 * N8;
+        if (H4 == 1 && i < 4) return c[i & 3];
+        return e[(i - 4 * H4) & 1];
+    }
+};
 template <>
 struct McStage<9> {  // 20 doubles = 8 + 8 + 4
     sd8 a, b;
@@ -757,21 +785,22 @@ hipError_t launch_mc_sample(int type, uint64_t seed, int64_t first, int64_t nsam
 }
 
 // Gt = G and d packed [k][t][n + 1] (row = g_0..g_{n-1}, d) followed by >= 1 KiB of zeros; given for
-// n = 3 / 6 / 9, which take the lane-per-sample kernel
+// n <= 9, which take the lane-per-sample kernel
 hipError_t launch_mc_score(const double *G, const double *Gt, const double *d, const double *Ms, const double *dmom,
                            int k, int n, int t, int64_t nsamp, int metric, int normalise, int all_at_once,
                            double gau_sigma, double *sim, double *like, hipStream_t s) {
-    if (Gt && (n == 3 || n == 6 || n == 9)) {
+    if (Gt && n >= 1 && n <= 9) {
         const unsigned blocks = (unsigned)((nsamp + 255) / 256);
         const bool lg = metric == MC_CCSHIFT;
 #define MC_LANES(LAG, NC)                                                                                \
     hipLaunchKernelGGL((mc_score_lanes<LAG, NC>), dim3(blocks), dim3(256), 0, s, Gt, Ms, dmom, k, t, nsamp, \
                        metric, normalise, all_at_once, gau_sigma, sim, like)
+#define MC_LANES_N(NC) case NC: if (lg) MC_LANES(true, NC); else MC_LANES(false, NC); break
         switch (n) {
-            case 3: if (lg) MC_LANES(true, 3); else MC_LANES(false, 3); break;
-            case 6: if (lg) MC_LANES(true, 6); else MC_LANES(false, 6); break;
-            default: if (lg) MC_LANES(true, 9); else MC_LANES(false, 9); break;
+            MC_LANES_N(1); MC_LANES_N(2); MC_LANES_N(3); MC_LANES_N(4); MC_LANES_N(5);
+            MC_LANES_N(6); MC_LANES_N(7); MC_LANES_N(8); MC_LANES_N(9);
         }
+#undef MC_LANES_N
 #undef MC_LANES
         return hipGetLastError();
     }

@@ -72,11 +72,12 @@ def test_shipped_shape_vs_pinned_oracle(gpu, metric):
             assert np.allclose(sim, ref, rtol=TOL, atol=1e-12), (norm, allat, np.abs(sim - ref).max())
 
 
-@pytest.mark.parametrize("n", [3, 6, 9, 5])
+@pytest.mark.parametrize("n", [3, 6, 9, 5, 1, 8, 11])
 @pytest.mark.parametrize("t", [2, 3, 4, 5, 6, 7, 9, 33])
 def test_short_and_odd_traces_both_kernels(gpu, n, t):
-    """Group / tail handling of the lane-per-sample kernel (n = 3 / 6 / 9: two-row groups in ping-pong, so
-    every residue of (t - 1) mod 4 is hit) and the moment kernel (any other n), ragged sample counts."""
+    """Group / tail handling of the lane-per-sample kernel (n <= 9: two-row groups in ping-pong, so every residue
+    of (t - 1) mod 4 is hit; 3 / 6 / 9 hand-written stages, the others the generic one) and the moment kernel
+    (n = 11), ragged sample counts."""
     rng = np.random.default_rng(100 * n + t)
     k, N = 4, 300
     G = rng.standard_normal((k, n, t))
@@ -218,12 +219,12 @@ def test_errors(gpu):
         si.sample_on_device("DC", 0)
     with pytest.raises(FwiError):
         si.sample_on_device("DC", 4, first_sample=-1)
-    with pytest.raises(FwiError, match="too large"):   # the moment kernel (n = 5) keeps k * n moments in LDS ...
-        si.score_samples(np.ones((400, 8)), np.ones((400, 5, 8)), np.ones((5, 3)))
+    with pytest.raises(FwiError, match="too large"):   # the moment kernel (n > 9) keeps k * n moments in LDS ...
+        si.score_samples(np.ones((400, 8)), np.ones((400, 12, 8)), np.ones((12, 3)))
 
 
 def test_many_traces_take_the_lane_kernel_without_an_lds_limit(gpu):
-    """... the lane-per-sample kernel (n = 3 / 6 / 9) has no such limit."""
+    """... the lane-per-sample kernel (n <= 9) has no such limit."""
     rng = np.random.default_rng(2)
     k, n, t, N = 400, 3, 16, 70
     G = rng.standard_normal((k, n, t))
