@@ -38,8 +38,8 @@ def test_c_client_matches_python_binding(gpu, tmp_path):
     # the same shot through the Python binding
     nz, ny, nx, nt, nrec = 40, 36, 44, 60, 5
     i = np.arange(nz * ny * nx, dtype=np.uint64)
-    c = (2000.0 + 500.0 * ((i * np.uint64(2654435761)) % np.uint64(2 ** 32) % np.uint64(1000)).astype(np.float32)
-         / np.float32(1000.0)).astype(np.float32).reshape(nz, ny, nx)
+    x = ((i * np.uint64(2654435761)) % np.uint64(1000)).astype(np.float32)   # size_t arithmetic in the C client
+    c = (np.float32(2000.0) + np.float32(500.0) * x / np.float32(1000.0)).astype(np.float32).reshape(nz, ny, nx)
     a = np.pi * 25.0 * (np.arange(nt) * 1.0e-3 - 0.04)
     wav = ((1.0 - 2.0 * a * a) * np.exp(-a * a)).astype(np.float32)
     rec = [[8, 6 + 5 * r, 7 + 6 * r] for r in range(nrec)]
