@@ -1,0 +1,71 @@
+"""Off-grid sources / receivers (full_waveform_inversion_amd/points.py): interpolation weights and, on the GPU,
+the adjoint identity of a shot with interpolated points."""
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd.points import Spread
+
+
+@pytest.mark.parametrize("shape", [(9, 11), (6, 7, 8)])
+def test_weights_interpolate_linear_fields_exactly(shape):
+    rng = np.random.default_rng(0)
+    nd = len(shape)
+    pts = rng.random((40, nd)) * (np.array(shape) - 1)
+    pts[0] = 0.0                                    # a corner node
+    pts[1] = np.array(shape) - 1                    # the far corner node
+    pts[2] = np.floor(pts[2])                       # an interior node
+    pts[3, 0] = shape[0] - 1                        # on the last plane, fractional elsewhere
+    S = Spread(pts, shape)
+    coef = rng.standard_normal(nd)
+    grids = np.meshgrid(*[np.arange(s, dtype=float) for s in shape], indexing="ij")
+    field = 0.7 + sum(c * g for c, g in zip(coef, grids))
+    nodes = field[tuple(S.idx.T)][None, :]          # (1, m) "time series" of one sample
+    assert np.allclose(S.gather(nodes)[0], 0.7 + pts @ coef, rtol=0, atol=1e-12)
+    assert np.allclose(np.bincount(S.owner, S.weights, minlength=S.n), 1.0, atol=1e-14)  # partition of unity
+    for i in (0, 1, 2):                              # points on nodes use that node only
+        assert np.sum(S.owner == i) == 1 and np.array_equal(S.idx[S.owner == i][0], pts[i].astype(int))
+    assert S.idx.dtype == np.int32 and S.idx.min() >= 0 and np.all(S.idx.max(axis=0) <= np.array(shape) - 1)
+
+
+def test_scatter_is_the_transpose_of_gather():
+    rng = np.random.default_rng(1)
+    S = Spread(rng.random((7, 3)) * [4, 5, 6], (5, 6, 7))
+    a, x = rng.standard_normal((13, 7)), rng.standard_normal((13, len(S.owner)))
+    assert abs(np.sum(S.scatter(a) * x) - np.sum(a * S.gather(x))) < 1e-12
+    assert S.scatter(a[:, 0] if S.n == 1 else a).shape == (13, len(S.owner))
+
+
+def test_out_of_grid_points_are_rejected():
+    with pytest.raises(ValueError):
+        Spread([[0.0, 9.5]], (8, 10))
+    with pytest.raises(ValueError):
+        Spread([[1.0, 2.0, 3.0]], (8, 10))
+
+
+@pytest.mark.gpu
+def test_shot_with_interpolated_points_keeps_the_adjoint_identity(gpu):
+    """<R F S w, r> == <w, S^T F^T R^T r> through the engine (fp64), and moving a receiver by a fraction of a cell
+    moves its trace continuously between the two node traces."""
+    from full_waveform_inversion_amd import Engine
+    from oracle import fwi_oracle as fo
+    rng = np.random.default_rng(3)
+    shape, h, order, nt = (30, 26, 34), 10.0, 8, 80
+    c = 2000.0 + 300.0 * rng.random(shape)
+    dt = 0.6 * fo.cfl_dt(c.max(), h, 3, order)
+    S = Spread([[14.3, 12.6, 16.2], [8.0, 9.5, 20.25]], shape)
+    R = Spread(np.column_stack([np.full(6, 5.5), np.linspace(4.2, 20.7, 6), np.linspace(6.1, 27.9, 6)]), shape)
+    w, r = rng.standard_normal((nt, 2)), rng.standard_normal((nt, 6))
+    with Engine(shape, h, dt, nt, order=order, npml=4, sigma_max=300.0, dtype="float64") as e:
+        d = R.gather(e.forward(c, (S.idx, S.scatter(w)), R.idx, save=True))
+        adj = S.gather(e.adjoint(R.scatter(r)))
+        assert np.isfinite(e.gradient()).all()
+        lhs, rhs = float(np.sum(d * r)), float(np.sum(w * adj))
+        assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+        # a receiver at x = 10 + f is the (1 - f, f) blend of the node traces at x = 10 and 11
+        wav = fo.ricker(nt, dt, 25.0)
+        src = [[15, 13, 17]]
+        nodes = e.forward(c, (src, wav), [[6, 10, 10], [6, 10, 11]], save=False)
+        for f in (0.0, 0.25, 0.9):
+            P = Spread([[6.0, 10.0, 10.0 + f]], shape)
+            tr = P.gather(e.forward(c, (src, wav), P.idx, save=False))[:, 0]
+            assert np.allclose(tr, (1 - f) * nodes[:, 0] + f * nodes[:, 1], rtol=0, atol=1e-13 * np.abs(nodes).max())
