@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -77,6 +77,11 @@ SIGNATURES = {
     "fwi_mc_invert": (C.c_int, [_I32, _I32, C.c_uint64, _I64, _I64, _D, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32,
                                 _P, _P, _P, _P, _P, C.POINTER(_D)]),
     "fwi_mc_sample": (C.c_int, [_I32, _I32, C.c_uint64, _I64, _I64, _D, _P, _P]),
+    "fwi_mc_plan_create": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _I64, C.POINTER(C.c_void_p)]),
+    "fwi_mc_plan_destroy": (None, [_P]),
+    "fwi_mc_plan_invert": (C.c_int, [_P, _I32, C.c_uint64, _I64, _I64, _D, _I32, _I32, _I32, _P, _P, _P, _P,
+                                     C.POINTER(_D), C.POINTER(_D)]),
+    "fwi_mc_plan_score": (C.c_int, [_P, _I64, _P, _I32, _I32, _I32, _P, _P, C.POINTER(_D), C.POINTER(_D)]),
 }
 MC_INVERSION_TYPES = {"full_mt": 0, "DC": 1, "single_force": 2, "DC_single_force_couple": 3,
                       "DC_single_force_no_coupling": 4, "DC_crack_couple": 5, "single_force_crack_no_coupling": 6}

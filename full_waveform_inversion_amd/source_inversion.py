@@ -282,3 +282,125 @@ def run(datadir, outdir, real_data_fnames, MT_green_func_fnames, single_force_gr
     best = get_synth_forward_model_most_likely_result(MTs, MTp, G, inversion_type, device)
     io.save_specific_waveforms_to_file(real, best, data_labels, uid, inversion_type, outdir)
     return MTs, MTp, MTp_absolute
+
+
+class MonteCarloPlan:
+    """The Green's functions, the data and all work buffers of one inversion problem resident on a
+    GPU (``fwi_mc_plan_*``): blocks of up to ``max_samples`` samples are drawn / scored without
+    re-uploading or re-allocating anything.  Use it to run more samples than one call can hold::
+
+        with MonteCarloPlan(real_data_array, green_func_array, max_samples=1 << 22) as plan:
+            best, total = None, 0.0
+            for first in range(0, N, 1 << 22):
+                M, frac, sim, like, like_sum = plan.invert("full_mt", min(1 << 22, N - first), seed, first)
+                total += like_sum            # posterior of a sample = like / total, once all blocks are in
+    """
+
+    def __init__(self, real_data_array, green_func_array, max_samples, device=0):
+        G, d = _f64(green_func_array), _f64(real_data_array)
+        if G.ndim != 3 or d.shape != (G.shape[0], G.shape[2]):
+            raise ValueError("shapes must be G (k, n, t), data (k, t)")
+        self.k, self.n, self.t = G.shape
+        self.max_samples = int(max_samples)
+        self._lib = _lib.load()
+        self._plan = C.c_void_p()
+        _lib.check(None, self._lib.fwi_mc_plan_create(device, self.k, self.n, self.t, _p(G), _p(d),
+                                                      self.max_samples, C.byref(self._plan)))
+
+    def close(self):
+        if self._plan is not None and self._plan.value:
+            self._lib.fwi_mc_plan_destroy(self._plan)
+        self._plan = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _modes(metric, normalise, all_at_once):
+        if metric not in _lib.MC_METRICS:
+            raise ValueError("comparison_metric must be one of %s" % sorted(_lib.MC_METRICS))
+        return _lib.MC_METRICS[metric], int(bool(normalise)), int(bool(all_at_once))
+
+    def invert(self, inversion_type, num_samples, seed=0, first_sample=0, M_amplitude=1.0, comparison_metric="VR",
+               perform_normallised_waveform_inversion=True, compare_all_waveforms_simultaneously=True,
+               return_samples=True):
+        """Draw and score one block on the device: ``(MTs or None, amp_frac or None, similarity,
+        likelihood, like_sum)``."""
+        if inversion_type not in _lib.MC_INVERSION_TYPES:
+            raise ValueError("inversion_type must be one of %s" % sorted(_lib.MC_INVERSION_TYPES))
+        N = int(num_samples)
+        M = np.empty((self.n, N)) if return_samples else None
+        frac = np.empty(N) if return_samples else None
+        sim, like = np.empty(N), np.empty(N)
+        total, ms = C.c_double(0.0), C.c_double(0.0)
+        m, nrm, aao = self._modes(comparison_metric, perform_normallised_waveform_inversion,
+                                  compare_all_waveforms_simultaneously)
+        _lib.check(None, self._lib.fwi_mc_plan_invert(
+            self._plan, _lib.MC_INVERSION_TYPES[inversion_type], int(seed), int(first_sample), N, float(M_amplitude),
+            m, nrm, aao, _p(M) if return_samples else None, _p(frac) if return_samples else None, _p(sim), _p(like),
+            C.byref(total), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return M, frac, sim, like, total.value
+
+    def score(self, MTs, comparison_metric="VR", perform_normallised_waveform_inversion=True,
+              compare_all_waveforms_simultaneously=True):
+        """Score one block of given samples ``(n, N)``: ``(similarity, likelihood, like_sum)``."""
+        M = _f64(MTs)
+        if M.ndim != 2 or M.shape[0] != self.n:
+            raise ValueError("MTs must be (n, N)")
+        N = M.shape[1]
+        sim, like = np.empty(N), np.empty(N)
+        total, ms = C.c_double(0.0), C.c_double(0.0)
+        m, nrm, aao = self._modes(comparison_metric, perform_normallised_waveform_inversion,
+                                  compare_all_waveforms_simultaneously)
+        _lib.check(None, self._lib.fwi_mc_plan_score(self._plan, N, _p(M), m, nrm, aao, _p(sim), _p(like),
+                                                     C.byref(total), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return sim, like, total.value
+
+
+def monte_carlo_best_of(real_data_array, green_func_array, num_samples, inversion_type="full_mt", seed=0,
+                        M_amplitude=1.0, comparison_metric="VR", perform_normallised_waveform_inversion=True,
+                        compare_all_waveforms_simultaneously=True, block=1 << 22, keep=1000, device=0):
+    """A run too large to return whole (``num_samples`` up to billions): blocks of ``block`` samples are
+    drawn and scored on the device, only the scores come back, and the ``keep`` most likely samples
+    are regenerated from ``(seed, index)`` at the end.  Returns ``(indices, MTs (n[+1], keep), MTp
+    (keep,), like_total)`` with ``MTp`` normalised over ALL ``num_samples`` (:847-848)."""
+    N = int(num_samples)
+    block = int(min(block, N))
+    best_like, best_idx, total = np.empty(0), np.empty(0, np.int64), 0.0
+    with MonteCarloPlan(real_data_array, green_func_array, block, device) as plan:
+        for first in range(0, N, block):
+            cnt = min(block, N - first)
+            _, _, _, like, s = plan.invert(inversion_type, cnt, seed, first, M_amplitude, comparison_metric,
+                                           perform_normallised_waveform_inversion,
+                                           compare_all_waveforms_simultaneously, return_samples=False)
+            total += s
+            like = np.where(np.isnan(like), -np.inf, like)
+            kk = min(keep, cnt)
+            top = np.argpartition(like, cnt - kk)[cnt - kk:]
+            best_like = np.concatenate([best_like, like[top]])
+            best_idx = np.concatenate([best_idx, top.astype(np.int64) + first])
+            if len(best_like) > keep:
+                sel = np.argpartition(best_like, len(best_like) - keep)[len(best_like) - keep:]
+                best_like, best_idx = best_like[sel], best_idx[sel]
+    order = np.argsort(-best_like, kind="stable")
+    best_like, best_idx = best_like[order], best_idx[order]
+    cols, fracs = [], []
+    for i in best_idx:  # counter-based sampler: any sample is a pure function of (seed, index)
+        M, f = sample_on_device(inversion_type, 1, seed, int(i), M_amplitude, device)
+        cols.append(M)
+        fracs.append(f)
+    MTs = np.hstack(cols)
+    if inversion_type in samplers.COUPLED_TYPES:
+        MTs = np.vstack((MTs, np.concatenate(fracs)))
+    return best_idx, MTs, best_like / total, total

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 7
+#define FWI_ABI_VERSION 8
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -211,6 +211,24 @@ int fwi_mc_invert(int32_t device, int32_t inversion_type, uint64_t seed, int64_t
                   double *samples_out /* (n, nsamp) or NULL */, double *frac_out /* nsamp or NULL */,
                   double *similarity_out /* nsamp */, double *likelihood_out /* nsamp or NULL */,
                   double *posterior_out /* nsamp or NULL */, double *kernel_ms_out /* or NULL */);
+
+/* A run in many blocks (N beyond one call's memory, or streamed): the plan keeps the Green's
+ * functions, the data and every work buffer on the device, so each block costs its kernels and its
+ * downloads only.  Blocks hold at most max_samples samples.  *like_sum_out receives the block's
+ * sum of likelihoods; the posterior over the whole run is likelihood / (sum of the blocks'
+ * like_sum) (:847-848), formed by the caller.  One plan per GPU, one host thread at a time. */
+typedef struct fwi_mc_plan fwi_mc_plan;
+int fwi_mc_plan_create(int32_t device, int32_t k, int32_t n, int32_t t, const double *green, const double *data,
+                       int64_t max_samples, fwi_mc_plan **out);
+void fwi_mc_plan_destroy(fwi_mc_plan *plan);
+int fwi_mc_plan_invert(fwi_mc_plan *plan, int32_t inversion_type, uint64_t seed, int64_t first_sample,
+                       int64_t nsamp, double amplitude, int32_t metric, int32_t normalise, int32_t all_at_once,
+                       double *samples_out /* (n, nsamp) or NULL */, double *frac_out /* nsamp or NULL */,
+                       double *similarity_out /* nsamp */, double *likelihood_out /* nsamp or NULL */,
+                       double *like_sum_out /* or NULL */, double *kernel_ms_out /* or NULL */);
+int fwi_mc_plan_score(fwi_mc_plan *plan, int64_t nsamp, const double *samples /* (n, nsamp) */, int32_t metric,
+                      int32_t normalise, int32_t all_at_once, double *similarity_out, double *likelihood_out,
+                      double *like_sum_out, double *kernel_ms_out);
 
 /* The device sampler alone: samples_out (n, nsamp), frac_out (nsamp) or NULL. */
 int fwi_mc_sample(int32_t device, int32_t inversion_type, uint64_t seed, int64_t first_sample, int64_t nsamp,

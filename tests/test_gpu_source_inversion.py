@@ -183,6 +183,48 @@ def test_two_ranks_share_one_run(gpu, tmp_path):
     assert np.allclose(np.concatenate([r["post"] for r in res]), post, rtol=1e-12, atol=0)
 
 
+def test_plan_blocks_equal_one_call(gpu):
+    """fwi_mc_plan_*: a run cut into blocks (device state kept between them) gives the samples, scores and
+    -- after the caller's renormalisation with the blocks' likelihood sums -- the posterior of one call."""
+    rng = np.random.default_rng(4)
+    typ, k, t, N = "DC_single_force_no_coupling", 6, 70, 2500
+    n = si.samplers.NUM_COMPONENTS[typ]
+    G = rng.standard_normal((k, n, t))
+    d = np.einsum("kjt,j->kt", G, rng.standard_normal(n)) + 0.1 * rng.standard_normal((k, t))
+    M, frac, sim, like, post = si.invert_on_device(d, G, N, typ, 3, 100, 0.8, "PCC", True, False)
+    got = []
+    with si.MonteCarloPlan(d, G, max_samples=1024) as plan:
+        for first in range(0, N, 1024):
+            got.append(plan.invert(typ, min(1024, N - first), 3, 100 + first, 0.8, "PCC", True, False))
+        assert np.array_equal(np.hstack([g[0] for g in got]), M) and np.array_equal(np.concatenate([g[1] for g in got]), frac)
+        assert np.array_equal(np.concatenate([g[2] for g in got]), sim)
+        like_all, total = np.concatenate([g[3] for g in got]), sum(g[4] for g in got)
+        assert np.array_equal(like_all, like) and np.allclose(like_all / total, post, rtol=1e-12, atol=0)
+        # given samples through the same plan, another metric / mode without re-creating it
+        s2, l2, tot2 = plan.score(M[:, :900], "VR", False, True)
+        ref = si.score_samples(d, G, M[:, :900], "VR", False, True)
+        assert np.array_equal(s2, ref[0]) and np.array_equal(l2, ref[1]) and abs(tot2 - ref[1].sum()) < 1e-9 * tot2
+        with pytest.raises(FwiError):
+            plan.invert(typ, 1025)                       # beyond the plan's capacity
+        with pytest.raises(FwiError):
+            plan.invert("full_mt", 10)                   # 6 components against 9-component Green's functions
+
+
+def test_best_of_a_run_too_large_to_return(gpu):
+    rng = np.random.default_rng(6)
+    typ, k, t, N = "full_mt", 5, 64, 300000
+    G = rng.standard_normal((k, 6, t))
+    Mt = si.sample_on_device(typ, 1, 17, 123456)[0]      # sample 123456 of the stream is the truth
+    d = np.einsum("kjt,j->kt", G, Mt[:, 0])
+    idx, MTs, MTp, total = si.monte_carlo_best_of(d, G, N, typ, seed=17, comparison_metric="VR",
+                                                  perform_normallised_waveform_inversion=False,
+                                                  compare_all_waveforms_simultaneously=False, block=65536, keep=50)
+    assert idx[0] == 123456 and np.allclose(MTs[:, 0], Mt[:, 0]) and MTs.shape == (6, 50)
+    assert np.all(np.diff(MTp) <= 0) and 0 < MTp.sum() < 1
+    _, _, _, like, post = si.invert_on_device(d, G, N, typ, 17, 0, 1.0, "VR", False, False, return_samples=False)
+    assert abs(total - like.sum()) < 1e-9 * total and np.allclose(MTp, np.sort(post)[::-1][:50], rtol=1e-10)
+
+
 def test_million_samples_best_is_truth(gpu):
     """Size-independent property at production scale: 2^20 samples, the planted source scores highest."""
     rng = np.random.default_rng(0)
