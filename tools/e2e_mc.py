@@ -5,6 +5,7 @@ the reference's shipped shape (k = 21, n = 9, t = 512), next to the kernel time:
   host    - samplers.draw on the host (NumPy, batched) + fwi_mc_score
   invert  - fwi_mc_invert: samples drawn on the device, everything returned (75 MB + 24 MB down)
   scores  - fwi_mc_invert with return_samples=False (only 16 MB of scores cross PCIe)
+  plan    - the same through fwi_mc_plan_invert, 16 blocks back to back (buffers and Green's functions resident)
 """
 import json
 import os
@@ -46,6 +47,15 @@ def main():
     rows["invert"] = (w, r[5])
     w, r = best(lambda: si.invert_on_device(d, G, N, typ, 1, 0, 1.0, "VR", False, False, False, 0, True))
     rows["scores"] = (w, r[5])
+    # a run in blocks through one plan: 16 x 2^20 samples, scores only (what monte_carlo_best_of does)
+    with si.MonteCarloPlan(d, G, N) as plan:
+        plan.invert(typ, N, 1, 0, 1.0, "VR", False, False, return_samples=False)
+        t0 = time.perf_counter()
+        kms = 0.0
+        for b in range(16):
+            plan.invert(typ, N, 1, b * N, 1.0, "VR", False, False, return_samples=False)
+            kms += plan.last_kernel_ms
+        rows["plan x16 (per block)"] = ((time.perf_counter() - t0) / 16, kms / 16)
     for name, (wall, kms) in rows.items():
         print(json.dumps({"path": name, "inversion_type": typ, "samples": N, "wall_ms": round(wall * 1e3, 2),
                           "score_kernel_ms": round(kms, 3), "samples_per_s_end_to_end": round(N / wall)}), flush=True)
