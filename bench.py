@@ -40,11 +40,22 @@ def cpu_baseline(w, sample_steps):
     t0 = time.perf_counter()
     p.forward(w.src_idx, wav, w.rec_idx, save=False)
     el = time.perf_counter() - t0
-    return {"value": int(np.prod(w.shape)) * sample_steps / el / 1e9, "unit": "Gpts/s", "cores": cores,
-            "kind": "port",
-            "sample": "same %s grid, first %d of %d time steps, fp64 OpenMP C port of the build's oracle "
-                      "(the reference has no such path), %.1f s" % ("x".join(map(str, w.shape)),
-                                                                    sample_steps, w.nt, el)}
+    out = {"value": int(np.prod(w.shape)) * sample_steps / el / 1e9, "unit": "Gpts/s", "cores": cores,
+           "kind": "port",
+           "sample": "same %s grid, first %d of %d time steps, fp64 OpenMP C port of the build's oracle "
+                     "(the reference has no such path), %.1f s" % ("x".join(map(str, w.shape)),
+                                                                   sample_steps, w.nt, el)}
+    # the NumPy form of the same oracle (what a "NumPy CPU path" of this scheme is): sliced-array stencil,
+    # effectively one core; two steps of the same grid are enough for a rate
+    from oracle import fwi_oracle as fo
+    q = fo.Propagator(w.c, w.h, w.dt, w.order, w.npml)
+    nsteps = 8
+    t0 = time.perf_counter()
+    q.forward(w.src_idx, wav[:nsteps], w.rec_idx, save=False)
+    el_np = time.perf_counter() - t0
+    out["numpy_1core"] = {"value": int(np.prod(w.shape)) * nsteps / el_np / 1e9, "unit": "Gpts/s", "cores": 1,
+                          "sample": "%d time steps of the NumPy oracle on the same grid, %.1f s" % (nsteps, el_np)}
+    return out
 
 
 def measured_traffic(kernel_name, shape):
