@@ -385,9 +385,10 @@ def monte_carlo_best_of(real_data_array, green_func_array, num_samples, inversio
                                            perform_normallised_waveform_inversion,
                                            compare_all_waveforms_simultaneously, return_samples=False)
             total += s
-            like = np.where(np.isnan(like), -np.inf, like)
-            kk = min(keep, cnt)
-            top = np.argpartition(like, cnt - kk)[cnt - kk:]
+            # candidates: everything above the current keep-th best (one vectorised compare per block;
+            # NaN likelihoods compare false and drop out)
+            thr = best_like.min() if len(best_like) >= keep else -np.inf
+            top = np.flatnonzero(like > thr)
             best_like = np.concatenate([best_like, like[top]])
             best_idx = np.concatenate([best_idx, top.astype(np.int64) + first])
             if len(best_like) > keep:
