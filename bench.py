@@ -99,6 +99,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if not args.single_device:
+        # a launcher may already have narrowed this process to its own GPU (HIP_VISIBLE_DEVICES /
+        # ROCR_VISIBLE_DEVICES): then the only visible ordinal is 0
+        from full_waveform_inversion_amd import _lib as _fl
+        ndev = _fl.device_count()
+        if ndev > 0:
+            local %= ndev
     if world != args.gpus:
         if rank == 0 and world > 1:
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)

@@ -33,6 +33,10 @@ def main():
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    from full_waveform_inversion_amd import _lib as _fl
+    ndev = _fl.device_count()  # a launcher may have narrowed this process to one visible GPU
+    if ndev > 0:
+        local %= ndev
     kw = {"nshots": a.shots} if a.shots else {}
     w = workloads.CONFIGS[a.config](a.scale, **kw)
     wav = w.wavelet()
