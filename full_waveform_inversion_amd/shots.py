@@ -20,6 +20,27 @@ class Shot:
     wavelet: np.ndarray          # (nt,) or (nt, nsrc)
     rec_idx: np.ndarray          # (nrec, ndim)
     d_obs: np.ndarray | None = None  # (nt, nrec)
+    # off-grid points (points.Spread): src_idx / rec_idx / wavelet then hold the expanded node lists and
+    # the data are gathered back to the points; see Shot.at_coordinates
+    src_spread: object = None
+    rec_spread: object = None
+
+    @classmethod
+    def at_coordinates(cls, src_xyz, wavelet, rec_xyz, shape, d_obs=None):
+        """A shot whose sources / receivers sit at fractional grid coordinates (multilinear interpolation)."""
+        from .points import Spread
+        S, R = Spread(src_xyz, shape), Spread(rec_xyz, shape)
+        return cls(S.idx, S.scatter(wavelet), R.idx, d_obs, S, R)
+
+    def forward(self, engine, save):
+        """Seismograms at this shot's receivers, ``(nt, nrec)``."""
+        d = engine.forward(None, (self.src_idx, self.wavelet), self.rec_idx, save=save)
+        return self.rec_spread.gather(d) if self.rec_spread is not None else d
+
+    def adjoint(self, engine, residual):
+        """Back-propagate a residual given at this shot's receivers (imaging into the engine's accumulator)."""
+        r = self.rec_spread.scatter(residual) if self.rec_spread is not None else residual
+        engine.adjoint(np.ascontiguousarray(r))
 
 
 def partition_shots(nshots, rank, world):
@@ -145,7 +166,7 @@ def model_data(engine, model, shots, exchange=None):
 
     def one(e, i):
         s = shots[i]
-        s.d_obs = e.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=False)
+        s.d_obs = s.forward(e, save=False)
 
     mine = partition_shots(len(shots), ex.rank, ex.world)
     if isinstance(engine, EnginePool):
@@ -179,9 +200,9 @@ def _sweep_shots(engine, shots, ex, objective):
         s = shots[i]
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
-        d = e.forward(None, (s.src_idx, s.wavelet), s.rec_idx, save=True)
+        d = s.forward(e, save=True)
         j, r = objective(d, s.d_obs)
-        e.adjoint(r)
+        s.adjoint(e, r)
         return j
 
     mine = partition_shots(len(shots), ex.rank, ex.world)
