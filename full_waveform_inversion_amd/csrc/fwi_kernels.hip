@@ -262,7 +262,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
     // the 4 elements right of it (one scalar load each).
     const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * twid);
-    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : poff;
+    // (idle lanes 4..59 all repeat lane 3's address: one cache line per wave instead of the eight their own
+    // vectors span -- those re-loads were a quarter of the kernel's L2 requests)
+    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : rowoff - 1;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
     // idle lanes write consecutive words of the trash row (a 16 B stride would be a 4-way bank conflict)
     const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : lane;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
         halo[i] = ld4(a.u_cur + g.off0 + (int64_t)zh * sz + xa);
     }
     const int64_t rowoff = g.off0 + (int64_t)z * sz + bx * TILE_X;
-    const int64_t eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : poff;
+    const int64_t eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TILE_X + (lane - 60) : rowoff - 1;
     const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
     const int ecol = (lane < 4) ? lane : (lane >= 60) ? 4 * (LROW4 - 1) + (lane - 60) : lane;
     const float edge = a.u_cur[eoff];
