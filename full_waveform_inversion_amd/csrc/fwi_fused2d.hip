@@ -16,6 +16,8 @@
 // No reference counterpart; arithmetic identical to step2d_tile / the oracle.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fwi_kernels.h"
 
 namespace fwi {
@@ -34,12 +36,22 @@ __device__ __forceinline__ float rcp1(float a) {
 
 }  // namespace
 
-// Tile geometry: interior FT x FT points, KS fused steps, radius R  ->  extended edge FT + 2 KS R.
-// Threads per workgroup (one workgroup per CU: the two LDS images take 74 KB).  PMC profile at 512:
-// 57 % of the wave cycles are waits (LDS round trips, three barriers per sub-step, the initial
-// global loads), the rest ~2400 instructions per wave.  Measured at 1024^2, us/step: 256 threads
-// 5.5, 512 4.1, 1024 3.85 (forward); the imaging variant spills at the 128-VGPR cap of 1024
-// threads and stays at 512 (5.5 vs 5.8).
+// Tile geometry: interior FT x FT points, KS fused steps, radius R  ->  extended edge FT + 2 HL.
+// One workgroup per CU (the three LDS images take 111 KB).
+//
+// The region that is still exact shrinks by R cells per sub-step on every side.  Each sub-step spreads the
+// ROWS of its own region densely over the threads (the sub-steps are instantiated separately, so the divisions
+// are by constants): 88, 80, 72, 64 rows of 24 groups for R = 4, i.e. 3 + 2 + 2 + 2 groups per thread instead
+// of the 3 + 3 + 3 + 3 of a fixed group-to-thread map, which has to cover the whole 24 x 96 image every time
+// and idles on the shrinking border (forward 3.85 -> 3.64, SAVE_Q 4.6 -> 3.8, IMAGE 5.6 -> 4.5 us/step at
+// 1024^2).  Whole rows only: consecutive lanes then walk consecutive 16-byte LDS words, which is bank-conflict
+// free; cutting the columns to the exact region too (2 + 2 + 2 + 1 groups) made half of all LDS cycles bank
+// conflicts and was slower (4.2 us/step).  A dynamic map means no per-thread state may be tied to a group, so
+// C sits in LDS beside the two fields and there are no inside-the-grid masks at all: outside the grid the
+// loaded C is 0, and a cell with C = 0 and u = 0 stays 0 -- the Dirichlet wall.  The imaging accumulators and
+// the final stores use a second, fixed map of the FT x FT interior.  Register pressure decides everything at
+// 1024 threads (128 VGPRs): the update writes each group back at once (holding a thread's groups to write
+// them together spilled, and a scratch reload waits for vmcnt(0), i.e. for every load in flight).
 template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE>
 __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
     constexpr int FNT = IMAGE ? 512 : 1024;
@@ -47,10 +59,12 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
     constexpr int E = FT + 2 * HL;       // extended tile edge (rows and columns)
     constexpr int E4 = E / 4;            // float4 groups per row
     constexpr int NG = E * E4;           // groups in the extended tile
-    constexpr int GPT = (NG + FNT - 1) / FNT;  // groups per thread
-    static_assert(E % 4 == 0 && HL % 4 == 0, "tile edges must be float4 aligned");
+    constexpr int NI = FT * (FT / 4);    // groups in the interior
+    constexpr int IPT = (NI + FNT - 1) / FNT;  // interior groups per thread
+    static_assert(E % 4 == 0 && HL % 4 == 0 && FT % 4 == 0, "tile edges must be float4 aligned");
     __shared__ q4 fa[E][E4];             // field A (starts as u^n)
     __shared__ q4 fb[E][E4];             // field B (starts as u^{n-1})
+    __shared__ q4 fc[E][E4];             // C = dt^2 c^2, 0 outside the grid
     __shared__ float dzs[E], dxs[E];     // damping profiles of the tile's rows / columns
 
     const int tid = threadIdx.x;
@@ -58,42 +72,34 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
     const int tz = blockIdx.x / ntx, tx = blockIdx.x % ntx;
     const int z0 = tz * FT - HL, x0 = tx * FT - HL;  // grid coordinates of extended (0, 0)
 
-    // ---- load: zero outside the grid (the padded arrays only carry 4 zero cells) -------------------
-    q4 Cg[GPT];
-    unsigned inside[GPT];  // 4-bit mask: which of the group's points lie inside the grid
+    // ---- load: zero outside the grid.  x0 and the 4-cell pad are multiples of 4, so a group is either left of
+    // the grid, or starts inside it (a group straddling the right edge reads the pad: u = 0, C = 0 there) ------
+    {
+        // Branch-free, all loads in flight before the first LDS write (a divergent `if`, or a select on the
+        // loaded value, made hipcc wait per group: 43 instead of 15 us per launch).  Groups outside the grid
+        // are pointed at the zero halo of the padded arrays -- row -1 / row nz, column -4 / the pad right of
+        // nx -- which holds exactly the zeros (u and C alike) they must see.
+        constexpr int GPT = (NG + FNT - 1) / FNT;
+        q4 va[GPT], vb[GPT], vc[GPT];
+        const int xpad = (g.nx + 3) & ~3;
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) {
-        const int gi = tid + i * FNT;
-        const int lz = gi / E4, l4 = gi % E4;
-        const int z = z0 + lz, x = x0 + 4 * l4;
-        q4 va = {{0.f, 0.f, 0.f, 0.f}}, vb = va, vc = va;
-        unsigned m = 0;
-        if (gi < NG && z >= 0 && z < g.nz && x + 3 >= 0 && x < g.nx) {
-            // groups are 16 B aligned in the padded layout (x0 and the 4-cell pad are multiples of 4);
-            // a group straddling the right edge reads pad zeros / is masked element-wise
-            const int64_t p = g.off0 + (int64_t)z * g.sz + x;
-            if (x >= 0 && x + 3 < g.nx) {
-                va = *reinterpret_cast<const q4 *>(a.u_cur + p);
-                vb = *reinterpret_cast<const q4 *>(a.u_prev + p);
-                vc = *reinterpret_cast<const q4 *>(a.C + p);
-                m = 0xF;
-            } else {
+        for (int i = 0; i < GPT; ++i) {
+            const int gi = min(tid + i * FNT, NG - 1);
+            const int lz = gi / E4, l4 = gi % E4;
+            const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
+            const int64_t p = g.off0 + (int64_t)zc * g.sz + xc;
+            va[i] = *reinterpret_cast<const q4 *>(a.u_cur + p);
+            vb[i] = *reinterpret_cast<const q4 *>(a.u_prev + p);
+            vc[i] = *reinterpret_cast<const q4 *>(a.C + p);
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j >= 0 && x + j < g.nx) {
-                        va.v[j] = a.u_cur[p + j];
-                        vb.v[j] = a.u_prev[p + j];
-                        vc.v[j] = a.C[p + j];
-                        m |= 1u << j;
-                    }
-            }
+        for (int i = 0; i < GPT; ++i) {
+            const int gi = tid + i * FNT;
+            if (gi >= NG) break;
+            fa[gi / E4][gi % E4] = va[i];
+            fb[gi / E4][gi % E4] = vb[i];
+            fc[gi / E4][gi % E4] = vc[i];
         }
-        if (gi < NG) {
-            fa[lz][l4] = va;
-            fb[lz][l4] = vb;
-        }
-        Cg[i] = vc;
-        inside[i] = m;
     }
     if (DAMP) {
         for (int i = tid; i < E; i += FNT) {
@@ -102,10 +108,11 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
             dxs[i] = (x >= 0 && x < g.nx) ? a.dx[x] : 0.f;
         }
     }
-    q4 gacc[GPT];
+    // fixed map of the interior (imaging accumulators, q prefetch, final stores): group ii = tid + i FNT
+    q4 gacc[IPT];
     if (IMAGE) {
 #pragma unroll
-        for (int i = 0; i < GPT; ++i) gacc[i] = {{0.f, 0.f, 0.f, 0.f}};
+        for (int i = 0; i < IPT; ++i) gacc[i] = {{0.f, 0.f, 0.f, 0.f}};
     }
     __syncthreads();
 
@@ -114,36 +121,36 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
     const int s0 = a.inj_start ? a.inj_start[blockIdx.x] : 0, s1 = a.inj_start ? a.inj_start[blockIdx.x + 1] : 0;
     const int r0 = a.rec_start ? a.rec_start[blockIdx.x] : 0, r1 = a.rec_start ? a.rec_start[blockIdx.x + 1] : 0;
 
-    for (int s = 0; s < KS; ++s) {
+    auto substep = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
         const int n = a.n0 + s * a.dn;  // global time-step index of this sub-step
         // imaging stride: q^n is stored / correlated for n % istride == 0 only, in slot n / istride
         const bool qstep = (SAVE_Q || IMAGE) && (a.istride <= 1 || n % a.istride == 0);
         float *const qslot = a.q_base + (int64_t)(a.istride <= 1 ? n : n / a.istride) * g.npts;
-        // Only the rows that must still be exact after this sub-step are updated: the exact region
-        // shrinks by R per sub-step towards the interior (trapezoid).  Rows only: the test is (nearly)
-        // wave-uniform; also cutting columns diverges lanes and measured slower (4.8 vs 4.1 us/step).
-        const int lo = (s + 1) * R, hi = E - (s + 1) * R;
+        // the region that must still be exact after this sub-step (compile-time: the loop is unrolled)
+        constexpr int lo = (s + 1) * R, hi = E - (s + 1) * R;
+        constexpr int c_lo = 0, w4 = E4, nact = (hi - lo) * w4;
+        constexpr int TRIPS = (nact + FNT - 1) / FNT;  // groups per thread in this sub-step
         // imaging: start fetching this step's q for the interior groups now, use it after the update
-        nt4 qv[GPT];
+        nt4 qv[IPT];
         if (IMAGE) {
 #pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                const int gi = tid + i * FNT;
-                const int lz = gi / E4, l4 = gi % E4;
-                const bool interior = gi < NG && lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
+            for (int i = 0; i < IPT; ++i) {
+                const int ii = tid + i * FNT;
+                const int lz = HL + ii / (FT / 4), l4 = HL / 4 + ii % (FT / 4);
+                const int z = z0 + lz, x = x0 + 4 * l4;
                 qv[i] = nt4{0.f, 0.f, 0.f, 0.f};
-                if (qstep && interior && inside[i] == 0xF)
-                    qv[i] = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(
-                        qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4)));
+                if (qstep && ii < NI && z < g.nz && x < g.nx)
+                    qv[i] = __builtin_nontemporal_load(
+                        reinterpret_cast<const nt4 *>(qslot + (int64_t)z * g.cx + x));
             }
         }
-        // ---- stencil update ---------------------------------------------------------------------------
+        // ---- stencil update of the active region --------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < GPT; ++i) {
+        for (int i = 0; i < TRIPS; ++i) {
             const int gi = tid + i * FNT;
-            if (gi >= NG) break;
-            const int lz = gi / E4, l4 = gi % E4;
-            if (lz < lo || lz >= hi) continue;
+            if (gi >= nact) break;
+            const int lz = lo + gi / w4, l4 = c_lo + gi % w4;
             const q4 c = cur[lz][l4];
             const q4 xl = cur[lz][max(l4 - 1, 0)], xr = cur[lz][min(l4 + 1, E4 - 1)];
             float X[12];
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
             q4 lap = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int k = R; k >= 1; --k) {
-                const q4 zm = cur[max(lz - k, 0)][l4], zp = cur[min(lz + k, E - 1)][l4];
+                const q4 zm = cur[lz - k][l4], zp = cur[lz + k][l4];  // lo >= R, hi <= E - R: in range
                 const float ck = a.ck[k];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -165,32 +172,25 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
                     lap.v[j] = fmaf(ck, t, lap.v[j]);
                 }
             }
-            const q4 up = prv[lz][l4];
+            const q4 up = prv[lz][l4], Cc = fc[lz][l4];
             q4 q, un;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                q.v[j] = Cg[i].v[j] * lap.v[j];
+                q.v[j] = Cc.v[j] * lap.v[j];
                 if (DAMP) {
                     const float d = dzs[lz] + dxs[4 * l4 + j];
                     un.v[j] = (fmaf(2.f, c.v[j], -(1.f - d) * up.v[j]) + q.v[j]) * rcp1(1.f + d);
                 } else {
                     un.v[j] = (2.f * c.v[j] - up.v[j]) + q.v[j];
                 }
-                if (!((inside[i] >> j) & 1u)) un.v[j] = 0.f;  // Dirichlet: zero outside the grid
             }
             prv[lz][l4] = un;  // in place: only this thread reads prv[lz][l4]
             if (SAVE_Q && qstep) {
+                const int z = z0 + lz, x = x0 + 4 * l4;
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
-                if (interior && inside[i]) {
-                    float *qp = qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
-                    if (inside[i] == 0xF) {
-                        nt4 v = {q.v[0], q.v[1], q.v[2], q.v[3]};
-                        __builtin_nontemporal_store(v, reinterpret_cast<nt4 *>(qp));
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if ((inside[i] >> j) & 1u) qp[j] = q.v[j];
-                    }
+                if (interior && z < g.nz && x < g.nx) {  // (compact rows are padded to cx: whole vector)
+                    nt4 v = {q.v[0], q.v[1], q.v[2], q.v[3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<nt4 *>(qslot + (int64_t)z * g.cx + x));
                 }
             }
         }
@@ -214,60 +214,46 @@ __global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a
         // ---- imaging: g += mu^{n+1} * q^n on the interior ---------------------------------------------
         if (IMAGE && qstep) {
 #pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                const int gi = tid + i * FNT;
-                if (gi >= NG) break;
-                const int lz = gi / E4, l4 = gi % E4;
-                const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
-                if (interior && inside[i]) {
-                    const float *qp = qslot + (int64_t)(z0 + lz) * g.cx + (x0 + 4 * l4);
-                    const q4 u = prv[lz][l4];
-                    if (inside[i] == 0xF) {
+            for (int i = 0; i < IPT; ++i) {
+                const int ii = tid + i * FNT;
+                if (ii >= NI) break;
+                const int lz = HL + ii / (FT / 4), l4 = HL / 4 + ii % (FT / 4);
+                const q4 u = prv[lz][l4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) gacc[i].v[j] = fmaf(u.v[j], qv[i][j], gacc[i].v[j]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if ((inside[i] >> j) & 1u) gacc[i].v[j] = fmaf(u.v[j], qp[j], gacc[i].v[j]);
-                    }
-                }
+                for (int j = 0; j < 4; ++j) gacc[i].v[j] = fmaf(u.v[j], qv[i][j], gacc[i].v[j]);
             }
         }
         // roles swap: prv now holds the newest field
         q4(*t)[E4] = cur;
         cur = prv;
         prv = t;
+    };
+    static_assert(KS == 2 || KS == 4, "sub-steps are spelled out below");
+    substep(std::integral_constant<int, 0>{});
+    substep(std::integral_constant<int, 1>{});
+    if constexpr (KS == 4) {
+        substep(std::integral_constant<int, 2>{});
+        substep(std::integral_constant<int, 3>{});
     }
 
     // ---- write the interior of the last two time levels (and the gradient contribution) -------------
 #pragma unroll
-    for (int i = 0; i < GPT; ++i) {
-        const int gi = tid + i * FNT;
-        if (gi >= NG) break;
-        const int lz = gi / E4, l4 = gi % E4;
-        const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
-        if (!interior || !inside[i]) continue;
+    for (int i = 0; i < IPT; ++i) {
+        const int ii = tid + i * FNT;
+        if (ii >= NI) break;
+        const int lz = HL + ii / (FT / 4), l4 = HL / 4 + ii % (FT / 4);
         const int z = z0 + lz, x = x0 + 4 * l4;
+        if (z >= g.nz || x >= g.nx) continue;  // (interior: z, x >= 0)
+        // a group straddling the right edge writes zeros into the pad columns: they are zero by construction
         const int64_t p = g.off0 + (int64_t)z * g.sz + x;
-        const q4 vc = cur[lz][l4], vp = prv[lz][l4];
-        if (inside[i] == 0xF) {
-            *reinterpret_cast<q4 *>(a.out_cur + p) = vc;
-            *reinterpret_cast<q4 *>(a.out_prev + p) = vp;
-            if (IMAGE) {
-                float *gp = a.g + (int64_t)z * g.cx + x;
-                q4 gv = *reinterpret_cast<const q4 *>(gp);
+        *reinterpret_cast<q4 *>(a.out_cur + p) = cur[lz][l4];
+        *reinterpret_cast<q4 *>(a.out_prev + p) = prv[lz][l4];
+        if (IMAGE) {
+            float *gp = a.g + (int64_t)z * g.cx + x;
+            q4 gv = *reinterpret_cast<const q4 *>(gp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gv.v[j] += gacc[i].v[j];
-                *reinterpret_cast<q4 *>(gp) = gv;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((inside[i] >> j) & 1u) {
-                    a.out_cur[p + j] = vc.v[j];
-                    a.out_prev[p + j] = vp.v[j];
-                    if (IMAGE) a.g[(int64_t)z * g.cx + x + j] += gacc[i].v[j];
-                }
+            for (int j = 0; j < 4; ++j) gv.v[j] += gacc[i].v[j];
+            *reinterpret_cast<q4 *>(gp) = gv;
         }
     }
 }
