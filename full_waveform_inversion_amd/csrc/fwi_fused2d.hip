@@ -53,8 +53,8 @@ __device__ __forceinline__ float rcp1(float a) {
 // 1024 threads (128 VGPRs): the update writes each group back at once (holding a thread's groups to write
 // them together spilled, and a scratch reload waits for vmcnt(0), i.e. for every load in flight).
 template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE>
-__global__ __launch_bounds__(IMAGE ? 512 : 1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
-    constexpr int FNT = IMAGE ? 512 : 1024;
+__global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
+    constexpr int FNT = 1024;  // all modes fit the 128-VGPR cap of 1024 threads (68 - 102 VGPRs, no scratch)
     constexpr int HL = (KS * R + 3) / 4 * 4;  // halo cells per side (float4 aligned)
     constexpr int E = FT + 2 * HL;       // extended tile edge (rows and columns)
     constexpr int E4 = E / 4;            // float4 groups per row
@@ -269,7 +269,7 @@ static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStr
     if (a.mode == 1)
         hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false>), grid, dim3(1024), 0, s, a, g);
     else if (a.mode == 2)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true>), grid, dim3(512), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true>), grid, dim3(1024), 0, s, a, g);
     else
         hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false>), grid, dim3(1024), 0, s, a, g);
     return hipGetLastError();
