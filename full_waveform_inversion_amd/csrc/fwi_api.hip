@@ -548,6 +548,13 @@ struct Impl {
         return ctx->fused2d && nt % FUSED2D_STEPS == 0 && (ctx->ckpt == 0 || ctx->ckpt % FUSED2D_STEPS == 0);
     }
 
+    // Steps taken by the fused kernel when nt is not a multiple of FUSED2D_STEPS (store-all mode only): the
+    // first nt - nt % FUSED2D_STEPS; the remaining 1-3 steps go one per launch.  0 = not applicable.
+    static int mixed_fused_steps(const fwi_ctx *ctx, int nt) {
+        if (!ctx->fused2d || ctx->ckpt != 0 || nt % FUSED2D_STEPS == 0) return 0;
+        return nt - nt % FUSED2D_STEPS;
+    }
+
     static int upload_points(fwi_ctx *ctx, int32_t nsrc, const int32_t *src_idx, int32_t nrec,
                              const int32_t *rec_idx) {
         int rc = upload_set(ctx, ctx->src, nsrc, src_idx, 1.0 / std::pow(ctx->cfg.h, ctx->gd.ndim));
@@ -660,8 +667,10 @@ struct Impl {
         auto none = [](int) -> T * { return nullptr; };
         auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
         const bool fused = use_fused(ctx, nt);  // 2-D: FUSED2D_STEPS time steps per launch
+        // a step count that is not a multiple of FUSED2D_STEPS: the bulk fused, the last 1-3 steps one per launch
+        const int nfused = mixed_fused_steps(ctx, nt);
         void *spare[2] = {ctx->fx[0], ctx->fx[1]};
-        if (fused && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
+        if ((fused || nfused) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
         if (save && K > 0) {
             for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
@@ -687,13 +696,17 @@ struct Impl {
             auto qo = [&](int n) -> T * {
                 return (save && n % ks == 0) ? q_store + (size_t)(n / ks) * g.npts : nullptr;
             };
-            if ((rc = run_steps(ctx, sw, 0, 1, nt, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1), qo, noq)))
+            if (nfused && (rc = run_fused(ctx, sw, spare, 0, 1, nfused, ctx->src, (const T *)ctx->wav, &ctx->rec, series,
+                                          T(1), save ? 1 : 0, q_store)))
+                return rc;
+            if ((rc = run_steps(ctx, sw, nfused, 1, nt - nfused, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1),
+                                qo, noq)))
                 return rc;
         }
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
-        if (fused) {  // the buffer pairs may have changed roles: keep ownership consistent
+        if (fused || nfused) {  // the buffer pairs may have changed roles: keep ownership consistent
             ctx->u[0] = sw.f[0];
             ctx->u[1] = sw.f[1];
             ctx->fx[0] = spare[0];
@@ -750,8 +763,9 @@ struct Impl {
             }
         };
         const bool fused = use_fused(ctx, nt);
+        const int nfused = mixed_fused_steps(ctx, nt);
         void *spare[2] = {ctx->fx[0], ctx->fx[1]};
-        if (fused && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
+        if ((fused || nfused) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
         bool imaged_all = false;  // the fused kernel pairs mu^{n+1} with q^n inside the launch (no lag)
         if (fused && image && K > 0) {
             // checkpointed, fused: recompute each segment's forward storing q into the slot buffer,
@@ -819,16 +833,29 @@ struct Impl {
             }
             q0 = carry;
         } else {
+            // steps nt-1 .. nfused one per launch (all of them when nfused == 0), lagged pairing; the pairing owed
+            // at the lower end, (mu^{nfused+1}, q^{nfused}), is the "last pairing" of that run
             const int ks = ctx->istride;
-            plan(nt - 1, 0, [&](int n) -> const T * {
+            plan(nt - 1, nfused, [&](int n) -> const T * {
                 return (image && n + 1 < nt && (n + 1) % ks == 0) ? q_store + (size_t)((n + 1) / ks) * g.npts
                                                                    : nullptr;
             });
             auto qi = [&](int n, const T *&p, const T *&p2) { p = pq[nt - 1 - n]; p2 = pq2[nt - 1 - n]; };
-            if ((rc = run_steps(ctx, sw, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, none, qi))) return rc;
-            q0 = q_store;
+            if ((rc = run_steps(ctx, sw, nt - 1, -1, nt - nfused, ctx->rec, amp, &ctx->src, series, rs, none, qi)))
+                return rc;
+            q0 = (nfused % ks == 0) ? q_store + (size_t)(nfused / ks) * g.npts : nullptr;
+            if (nfused) {
+                // ... then the first nfused steps, FUSED2D_STEPS per launch (pairing inside the launch, no lag)
+                if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
+                sw.prev_n = -1;
+                if (image && q0) HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
+                if ((rc = run_fused(ctx, sw, spare, nfused - 1, -1, nfused, ctx->rec, amp, &ctx->src, series, rs,
+                                    image ? 2 : 0, q_store)))
+                    return rc;
+                imaged_all = true;
+            }
         }
-        if (fused) {  // the buffer pairs may have changed roles: keep ownership consistent
+        if (fused || nfused) {  // the buffer pairs may have changed roles: keep ownership consistent
             ctx->u[0] = sw.f[0];
             ctx->u[1] = sw.f[1];
             ctx->fx[0] = spare[0];

@@ -422,7 +422,7 @@ def test_device_vector_algebra(gpu, shape):
 
 
 @pytest.mark.parametrize("shape,dtype,tol,nt", [((24, 20, 32), "float32", TOL32, 41), ((24, 20, 31), "float64", TOL64, 41),
-                                                ((48, 64), "float32", TOL32, 41),    # 2-D, one step per launch
+                                                ((48, 64), "float32", TOL32, 41),    # 2-D, 40 steps fused + 1 single
                                                 ((70, 131), "float32", TOL32, 40)])  # 2-D, 4 steps per launch
 @pytest.mark.parametrize("stride", [2, 3, 7])
 def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, nt, stride):
@@ -466,6 +466,26 @@ def test_image_stride_shrinks_the_store(gpu):
         d = e.forward(None, ([[128, 128, 128]], w), [[120, 128, 128]], save=True)
         e.adjoint(np.ones_like(d))
         assert np.isfinite(e.gradient()).all()
+
+
+@pytest.mark.parametrize("nt", [5, 41, 42, 43])
+def test_2d_step_counts_off_the_fused_multiple(gpu, nt):
+    """nt % 4 != 0 in 2-D: the bulk runs 4 steps per launch, the last 1-3 steps one per launch; the imaging
+    pairings of the two conventions (in-launch vs lagged) must tile the time axis exactly once."""
+    rng = np.random.default_rng(nt)
+    shape, h, order, npml = (60, 90), 8.0, 8, 5
+    c = 1800.0 + 900.0 * rng.random(shape)
+    dt = 0.6 * fo.cfl_dt(c.max(), h, 2, order)
+    src = np.stack([rng.integers(0, s, 2) for s in shape], 1)
+    rec = np.stack([rng.integers(0, s, 9) for s in shape], 1)
+    w = rng.standard_normal((nt, 2))
+    p = CPropagator(c, h, dt, order, npml)
+    d = p.forward(src, w, rec)
+    r = d + 0.2 * np.abs(d).max() * rng.standard_normal(d.shape)
+    a = p.adjoint(r)
+    o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r)
+    assert o["kernel"] == "step2d_fused"
+    assert rel(o["seis"], d) < TOL32 and rel(o["adj_src"], a) < TOL32 and rel(o["grad_c"], p.gradient()) < 3 * TOL32
 
 
 def test_device_lbfgs_matches_host_lbfgs(gpu):
