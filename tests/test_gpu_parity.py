@@ -476,8 +476,10 @@ def test_2d_step_counts_off_the_fused_multiple(gpu, nt):
     shape, h, order, npml = (60, 90), 8.0, 8, 5
     c = 1800.0 + 900.0 * rng.random(shape)
     dt = 0.6 * fo.cfl_dt(c.max(), h, 2, order)
-    src = np.stack([rng.integers(0, s, 2) for s in shape], 1)
+    src = np.stack([rng.integers(4, s - 4, 2) for s in shape], 1)
     rec = np.stack([rng.integers(0, s, 9) for s in shape], 1)
+    rec[:2] = src                      # receivers on the source nodes: data from the first step on
+    rec[2] = src[0] + [2, 3]
     w = rng.standard_normal((nt, 2))
     p = CPropagator(c, h, dt, order, npml)
     d = p.forward(src, w, rec)
