@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-point updates/s of the 3-D 256^3 O(8) acoustic stencil.
 
-One "step" = one full shot of BASELINE.json configs[3] (256^3 constant velocity,
-1000 time steps, O(8), fp32) through fwi_forward() on one MI355X.  With N > 1
-(launched by torch.distributed.run, one process per GPU) every rank runs its
-own shot per step -- shots are independent -- and the K steps of the timed
-region form one gradient evaluation over N*K shots, closed by the path's one
-real exchange: ONE RCCL all-reduce of the model-sized gradient accumulator
-("an RCCL all-reduce ... only for the final gradient sum", north_star), inside
-the timed region.  The reported value is the aggregate over ranks.  torch is used only for the
-rendezvous / barrier / max-over-ranks (gloo); the data path is HIP + RCCL
-behind the C-ABI.
+One "step" = one full shot of BASELINE.json configs[3] (256^3 constant velocity, 1000 time steps, O(8),
+fp32) through fwi_forward() on one MI355X.  With N > 1 (launched by torch.distributed.run, one process
+per GPU) every rank runs its own shot per step -- shots are independent -- and the K steps of the timed
+region form one gradient evaluation over N*K shots, closed by the path's one real exchange: ONE RCCL
+all-reduce of the model-sized gradient accumulator ("an RCCL all-reduce ... only for the final gradient
+sum", north_star), inside the timed region.  The reported value is the aggregate over ranks.
+
+No torch in this process: the launcher only provides RANK / WORLD_SIZE / MASTER_*; the control plane
+(unique-id hand-off, barriers) is the package's stdlib TCP rendezvous, the data path is HIP + RCCL behind
+the C-ABI, and the max-over-ranks of the elapsed time goes through RCCL too (fwi_allreduce_f64_max).
+With N > 1 any RCCL failure is fatal (non-zero exit): there is no host-side fallback for the sum.
+
+At N = 1 the same invocation also runs three short extra legs and reports them in the same JSON line
+(`legs`, and `roofline.hbm_regime`): the 512^3 forward run (working set past the 256 MiB Infinity Cache:
+the honest HBM number), the 256^3 gradient shot (forward + store, adjoint + imaging) and configs[1]
+(2-D 1024^2 x 2000 steps).  `--leg NAME` runs one leg alone (what the rocprofv3 passes use).
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -24,7 +31,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0        # same guide: measured float4 copy, the achievable ceiling
 BYTES_PER_UPDATE = 16        # read u_cur, u_prev, C; write u_next (fp32)
+MALL_BYTES = 256 << 20       # Infinity Cache
 
 
 def cpu_baseline(w, sample_steps):
@@ -40,39 +49,97 @@ def cpu_baseline(w, sample_steps):
     t0 = time.perf_counter()
     p.forward(w.src_idx, wav, w.rec_idx, save=False)
     el = time.perf_counter() - t0
-    out = {"value": int(np.prod(w.shape)) * sample_steps / el / 1e9, "unit": "Gpts/s", "cores": cores,
+    out = {"value": round(int(np.prod(w.shape)) * sample_steps / el / 1e9, 3), "unit": "Gpts/s", "cores": cores,
            "kind": "port",
            "sample": "same %s grid, first %d of %d time steps, fp64 OpenMP C port of the build's oracle "
                      "(the reference has no such path), %.1f s" % ("x".join(map(str, w.shape)),
                                                                    sample_steps, w.nt, el)}
     # the NumPy form of the same oracle (what a "NumPy CPU path" of this scheme is): sliced-array stencil,
-    # effectively one core; two steps of the same grid are enough for a rate
+    # effectively one core; a few steps of the same grid are enough for a rate
     from oracle import fwi_oracle as fo
     q = fo.Propagator(w.c, w.h, w.dt, w.order, w.npml)
-    nsteps = 8
+    nsteps = 4
     t0 = time.perf_counter()
     q.forward(w.src_idx, wav[:nsteps], w.rec_idx, save=False)
     el_np = time.perf_counter() - t0
-    out["numpy_1core"] = {"value": int(np.prod(w.shape)) * nsteps / el_np / 1e9, "unit": "Gpts/s", "cores": 1,
+    out["numpy_1core"] = {"value": round(int(np.prod(w.shape)) * nsteps / el_np / 1e9, 4), "unit": "Gpts/s",
+                          "cores": 1,
                           "sample": "%d time steps of the NumPy oracle on the same grid, %.1f s" % (nsteps, el_np)}
     return out
 
 
-def measured_traffic(kernel_name, shape):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
-
-    PMC counters cannot be collected inside this process; the numbers come from separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, condensed by
-    tools/summarize_profile.py.  Only quoted when kernel and grid match what is being run.
-    """
-    path = os.path.join(ROOT, "profiles", "r01_step3d_stream_%d.json" % shape[0])
+def measured_traffic(leg):
+    """Fabric-side bytes per launch of `leg`'s dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r02_traffic.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of `bench.py --leg <leg>`), or None.  PMC counters cannot be collected in-process."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     try:
-        prof = json.load(open(path))
+        ent = json.load(open(path)).get(leg)
     except (OSError, ValueError):
         return None, None
-    if kernel_name not in prof.get("kernel", "") or len(set(shape)) != 1:
+    if not ent:
         return None, None
-    return prof["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return ent.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT) + "#" + leg
+
+
+def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, exchange=None, barrier=None,
+            max_over_ranks=None):
+    """Time `steps` shots of a workload; returns (workload, per-shot wall s, kernel us/launch, info)."""
+    from full_waveform_inversion_amd import Engine
+    w = make_workload()
+    wav = w.wavelet()
+    model = w.c.astype(np.float32)
+    kw = dict(order=w.order, npml=w.npml, device=device)
+    kw.update(engine_kw or {})
+    e = Engine(w.shape, w.h, w.dt, w.nt, **kw)
+    try:
+        t_sm = time.perf_counter()
+        e.set_model(model)
+        set_model_ms = 1e3 * (time.perf_counter() - t_sm)
+        ex = exchange(e) if exchange else None
+
+        def step():
+            d = e.forward(None, (w.src_idx[:1], wav), w.rec_idx, save=grad)
+            ms = e.last_loop_ms()
+            if grad:
+                e.adjoint(d)  # residual = the data themselves: same work as any residual
+                ms += e.last_loop_ms()
+            return ms
+
+        for _ in range(warmup):
+            step()
+        if ex is not None:
+            e.allreduce_gradient()  # warm the communicator (the first collective sets up the rings)
+        if barrier:
+            barrier()
+        e.synchronize()
+        t0 = time.perf_counter()
+        loop_ms = [step() for _ in range(steps)]
+        if ex is not None:
+            e.allreduce_gradient()  # the shot loop's one exchange: sum of the per-rank gradients
+        e.synchronize()
+        if barrier:
+            barrier()
+        el = time.perf_counter() - t0
+        if max_over_ranks:
+            el = max_over_ranks(e, el)
+        sweeps = 2 if grad else 1
+        info = {"kernel": e.kernel_name, "set_model_ms": round(set_model_ms, 1),
+                "rccl_ranks": ex.rccl_ranks if ex is not None else None}
+        return w, el, 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps), info
+    finally:
+        e.close()
+
+
+def roofline_entry(leg, w, kern_us, bpu, bound, note):
+    npts = int(np.prod(w.shape))
+    achieved = bpu * npts / (kern_us * 1e-6) / 1e9
+    traffic, src = measured_traffic(leg)
+    return {"bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_achievable_hbm": round(achieved / HBM_COPY_GBS, 4),
+            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": src,
+            "algorithmic_bytes_per_launch": bpu * npts, "kernel_avg_us": round(kern_us, 3), "note": note}
 
 
 def main():
@@ -80,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grid", type=int, default=256, help="cube edge (256 = BASELINE config)")
+    ap.add_argument("--grid", type=int, default=256, help="cube edge of the headline leg (256 = BASELINE config)")
     ap.add_argument("--nt", type=int, default=1000)
     ap.add_argument("--npml", type=int, default=0)
     ap.add_argument("--kernel", default="auto")
@@ -88,166 +155,164 @@ def main():
     ap.add_argument("--image-stride", type=int, default=1,
                     help="gradient mode: store / correlate the forward term every S-th step (fwi_config.image_stride)")
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
-                    help="forward: the headline stencil run; gradient: forward(save) + adjoint(imaging) per step")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal on a 1-GPU box: every rank uses device 0 (RCCL refuses duplicate GPUs, "
-                         "so this exercises the flagged fallback exchange)")
-    ap.add_argument("--cpu-steps", type=int, default=1000,
-                    help="time steps of the CPU baseline sample (1000 = the whole shot, ~12 s on 16 cores); 0 = skip")
+                    help="headline leg: forward = the stencil run; gradient = forward(save) + adjoint(imaging) per step")
+    ap.add_argument("--leg", default="all", choices=["all", "headline", "hbm", "gradient", "cfg2"],
+                    help="all: headline + (at N = 1) the three extra legs; or one leg alone (profiling passes)")
+    ap.add_argument("--leg-nt", type=int, default=0, help="time steps of a --leg run (0 = the leg's own)")
+    ap.add_argument("--cpu-steps", type=int, default=200,
+                    help="time steps of the CPU baseline sample (200 of the 1000 steps, ~3 s on 16 cores); 0 = skip")
     args = ap.parse_args()
+
+    # one node, one process per GPU: the driver only supports dmabuf IPC, and the RCCL bootstrap of a
+    # single-node job belongs on loopback (the container's hostname may not resolve)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
-    if not args.single_device:
-        # a launcher may already have narrowed this process to its own GPU (HIP_VISIBLE_DEVICES /
-        # ROCR_VISIBLE_DEVICES): then the only visible ordinal is 0
-        from full_waveform_inversion_amd import _lib as _fl
-        ndev = _fl.device_count()
-        if ndev > 0:
-            local %= ndev
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from full_waveform_inversion_amd import _lib as _fl
+    ndev = _fl.device_count()  # a launcher may have narrowed this process to its own GPU: then ordinal 0
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
+    local %= ndev
     if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world > 1 and world > ndev and "LOCAL_RANK" in os.environ and ndev > 1:
+        sys.exit("bench.py: %d ranks but only %d visible GPUs (RCCL refuses two ranks on one device)" % (world, ndev))
 
-    from full_waveform_inversion_amd import Engine, workloads
+    from full_waveform_inversion_amd import workloads
+    from full_waveform_inversion_amd.rendezvous import Rendezvous
+    from full_waveform_inversion_amd.shots import RcclExchange
 
-    w = workloads.cfg4(args.grid / 256.0, npml=args.npml)
-    w.nt = args.nt
-    wav = w.wavelet()
-    model = w.c.astype(np.float32)
-    e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local, kernel=args.kernel,
-               zchunk=args.zchunk, image_stride=args.image_stride)
-    t_sm = time.perf_counter()
-    e.set_model(model)
-    set_model_ms = 1e3 * (time.perf_counter() - t_sm)  # host padding + H2D, once per model (not timed)
-    exchange = "none"
-    if world > 1:
-        # The gradient sum goes over RCCL (xGMI), straight from the C-ABI.  Should the communicator
-        # fail to come up on every rank, the sum is still performed -- over the gloo control plane,
-        # on host copies -- and the JSON line says so; nothing is skipped silently.
-        from full_waveform_inversion_amd import FwiError
+    rdzv = Rendezvous.from_env(timeout=float(os.environ.get("FWI_RDZV_TIMEOUT", "300"))) if world > 1 else None
+
+    def exchange(e):
+        # a communicator that neither comes up nor fails must not hang the job: hard exit with a traceback
+        faulthandler.dump_traceback_later(float(os.environ.get("FWI_COMM_INIT_TIMEOUT", "300")), exit=True)
         try:
-            ids = [Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            # ncclCommInitRank in a helper thread (ctypes drops the GIL): a communicator that neither
-            # comes up nor fails within the limit is treated like one that failed
-            import threading
-            res = {}
+            return RcclExchange(e, rdzv)
+        finally:
+            faulthandler.cancel_dump_traceback_later()
 
-            def init():
-                try:
-                    e.comm_init(rank, world, ids[0])
-                    res["ok"] = True
-                except FwiError as ex:
-                    res["err"] = str(ex)
-
-            th = threading.Thread(target=init, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("FWI_COMM_INIT_TIMEOUT", "180")))
-            if res.get("ok"):
-                ok, why = 1, ""
-            else:
-                ok, why = 0, res.get("err", "ncclCommInitRank did not return within the time limit")
-        except FwiError as ex:
-            ok, why = 0, str(ex)
-        import torch
-        flag = torch.tensor([ok])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            exchange = "one rccl allreduce of the gradient accumulator after the K shots (timed)"
-        else:
-            exchange = "GLOO FALLBACK (rccl communicator failed: %s): host allreduce after the K shots (timed)" % (
-                why or "on another rank")
-            if rank == 0:
-                print("warning: " + exchange, file=sys.stderr)
-
-    def exchange_gradient():
-        if exchange.startswith("one rccl"):
-            e.allreduce_gradient()
-        elif world > 1:
-            import torch
-            t = torch.from_numpy(e.gradient("slowness2"))
-            dist.all_reduce(t)
+    def max_over_ranks(e, el):
+        return e.allreduce_f64([el], op="max")[0]
 
     grad = args.mode == "gradient"
+    S = max(1, args.image_stride)
 
-    def step():
-        d = e.forward(None, (w.src_idx, wav), w.rec_idx, save=grad)
-        ms = e.last_loop_ms()
-        if grad:
-            e.adjoint(d)  # residual = the data themselves: same work as any residual
-            ms += e.last_loop_ms()
-        return ms
+    def headline_workload():
+        w = workloads.cfg4(args.grid / 256.0, npml=args.npml)
+        w.nt = args.nt
+        return w
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        exchange_gradient()  # warm the communicator (first collective sets up the rings)
-    if dist is not None:
-        dist.barrier()
-    e.synchronize()
-    t0 = time.perf_counter()
-    loop_ms = [step() for _ in range(args.steps)]
-    if world > 1:
-        exchange_gradient()  # the shot loop's one exchange: sum of the per-rank gradients
-    e.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+    out = None
+    if args.leg in ("all", "headline"):
+        w, el, kern_us, info = run_leg(
+            headline_workload, local, args.steps, args.warmup, grad=grad,
+            engine_kw=dict(kernel=args.kernel, zchunk=args.zchunk, image_stride=S),
+            exchange=exchange if world > 1 else None, barrier=rdzv.barrier if rdzv else None,
+            max_over_ranks=max_over_ranks if world > 1 else None)
+        if rank == 0:
+            npts = int(np.prod(w.shape))
+            sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
+            # forward+save 20 B; adjoint + paired imaging 24 B (SURVEY s.8d prices the unpaired form at 28 B)
+            if grad and S > 1:  # every S-th step stores q (+4 B) / reads q and read-modify-writes g (+12 B)
+                bpu = ((16 + 4.0 / S) + (16 + 12.0 / S)) / 2.0
+            else:
+                bpu = (20 + 24) / 2.0 if grad else BYTES_PER_UPDATE
+            value = world * args.steps * npts * w.nt * sweeps / el / 1e9
+            resident = 3 * npts * 4 <= MALL_BYTES and not grad
+            out = {
+                "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic" +
+                          (" (forward+adjoint sweeps)" if grad else ""),
+                "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "set_model_ms": info["set_model_ms"],
+                "config": {"workload": "configs[3]: 3-D %s constant velocity, 1 shot/GPU/step, %d time steps, "
+                                       "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
+                           "kernel": info["kernel"], "image_stride": S,
+                           "parallelism": "shot-parallel x%d" % world,
+                           "exchange": "none" if world == 1 else
+                                       "one rccl allreduce of the gradient accumulator after the K shots (timed)",
+                           "rccl_ranks": info["rccl_ranks"], "control_plane": "stdlib tcp rendezvous (no torch)"},
+                "roofline": roofline_entry(
+                    "headline" if (args.grid == 256 and not grad) else "other", w, kern_us, bpu,
+                    "infinity-cache-resident" if resident else "hbm",
+                    "algorithmic %g B/update x %d updates per launch / HIP-event time of the %d-launch loop(s); "
+                    "wavefield working set 3 x %d MiB%s" % (
+                        bpu, npts, w.nt * sweeps, npts * 4 >> 20,
+                        " fits the 256 MiB Infinity Cache: the fraction of the 8 TB/s HBM peak is kept for "
+                        "continuity, the HBM-regime number is roofline.hbm_regime" if resident else "")),
+            }
+
+    extra = world == 1 and rank == 0 and not grad and args.grid == 256
+    legs = {}
+    want = (lambda name: args.leg == name or (args.leg == "all" and extra))
+
+    if want("hbm"):
+        def wl():
+            w = workloads.cfg4(2.0)
+            w.nt = args.leg_nt or 300
+            return w
+        w, el, kern_us, info = run_leg(wl, local, 3, 1)
+        r = roofline_entry("hbm", w, kern_us, BYTES_PER_UPDATE, "hbm",
+                           "512^3 forward, %d steps x 3 shots: working set 3 x 512 MiB, past the Infinity Cache" % w.nt)
+        r["workload"] = "3-D 512x512x512 constant velocity, O(8), %d time steps" % w.nt
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
+        r["kernel"] = info["kernel"]
+        legs["hbm"] = r
+    if want("gradient"):
+        def wl():
+            w = workloads.cfg4(1.0)
+            w.nt = args.leg_nt or 1000
+            return w
+        w, el, kern_us, info = run_leg(wl, local, 3, 1, grad=True)
+        r = roofline_entry("gradient", w, kern_us, 22.0, "hbm",
+                           "256^3 gradient shot: forward + store (20 B/update), adjoint + paired imaging "
+                           "(24 B/update); the forward-term store (%.1f GiB) streams through HBM"
+                           % (w.nt * int(np.prod(w.shape)) * 4 / 2.0 ** 30))
+        r["workload"] = "configs[3] grid, forward(save) + adjoint(imaging), %d time steps" % w.nt
+        r["Gpts_per_s_both_sweeps"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
+        r["ms_per_shot_gradient"] = round(1e3 * el / 3, 2)
+        r["kernel"] = info["kernel"]
+        legs["gradient"] = r
+    if want("cfg2"):
+        def wl():
+            w = workloads.cfg2(1.0)
+            if args.leg_nt:
+                w.nt = args.leg_nt
+            return w
+        w, el, kern_us, info = run_leg(wl, local, 10, 2)
+        r = roofline_entry("cfg2", w, kern_us, BYTES_PER_UPDATE, "lds+valu (fields are L2-resident: 3 x 4 MiB)",
+                           "configs[1]; kernel_avg_us is per TIME STEP (the fused kernel advances 4 per launch); "
+                           "the fraction of the HBM peak is quoted for continuity only -- see DESIGN.md s.4 for "
+                           "the LDS / VALU bound this kernel is measured against")
+        r["workload"] = "configs[1]: 2-D 1024x1024 layered, 1 shot, %d steps, O(8) + absorbing border" % w.nt
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
+        r["ms_per_shot"] = round(1e3 * el / 10, 3)
+        r["kernel"] = info["kernel"]
+        legs["cfg2"] = r
 
     if rank == 0:
-        npts = int(np.prod(w.shape))
-        sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
-        # forward+save 20 B; adjoint + paired imaging 24 B (SURVEY s.8d prices the unpaired form at 28 B)
-        S = max(1, args.image_stride)
-        if grad and S > 1:  # every S-th step stores q (+4 B) / reads q and read-modify-writes g (+12 B)
-            bpu = ((16 + 4.0 / S) + (16 + 12.0 / S)) / 2.0
-        else:
-            bpu = (20 + 24) / 2.0 if grad else BYTES_PER_UPDATE
-        updates = npts * w.nt * sweeps
-        value = world * args.steps * updates / el / 1e9
-        kern_us = 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps)  # avg launch-to-launch time per step kernel
-        achieved = bpu * npts / (kern_us * 1e-6) / 1e9
-        traffic, traffic_src = (None, None) if grad else measured_traffic(e.kernel_name, w.shape)
-        out = {
-            "metric": "stencil grid-point-updates/sec (Gpts/s), 3-D O(8) acoustic" +
-                      (" (forward+adjoint sweeps)" if grad else ""),
-            "value": round(value, 3), "unit": "Gpts/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "set_model_ms": round(set_model_ms, 1),
-            "config": {"workload": "configs[3]: 3-D %s constant velocity, 1 shot/GPU/step, %d time steps, "
-                                   "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
-                       "kernel": e.kernel_name, "image_stride": S, "parallelism": "shot-parallel x%d" % world,
-                       "exchange": exchange},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bpu * npts,
-                         "kernel_avg_us": round(kern_us, 2),
-                         "note": "algorithmic %g B/update x %d updates per launch / HIP-event time of the "
-                                 "%d-launch loop(s); wavefield working set 3 x %d MiB" % (bpu, npts, w.nt * sweeps,
-                                                                                         npts * 4 >> 20)},
-        }
-        if args.cpu_steps > 0 and world == 1 and not grad:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
+        if out is None:  # a single extra leg on its own (profiling pass)
+            out = {"leg": args.leg}
+        if "hbm" in legs and "roofline" in out:
+            out["roofline"]["hbm_regime"] = legs.pop("hbm")
+        if legs:
+            out["legs"] = legs
+        if args.cpu_steps > 0 and extra and args.leg == "all":
+            out["cpu_baseline"] = cpu_baseline(headline_workload(), args.cpu_steps)
         print(json.dumps(out))
-    e.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

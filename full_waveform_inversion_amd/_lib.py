@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -57,6 +57,9 @@ SIGNATURES = {
     "fwi_comm_init": (C.c_int, [_P, _I32, _I32, _P]),
     "fwi_allreduce_gradient": (C.c_int, [_P]),
     "fwi_allreduce_f64": (C.c_int, [_P, C.POINTER(_D), _I32]),
+    "fwi_allreduce_f64_max": (C.c_int, [_P, C.POINTER(_D), _I32]),
+    "fwi_comm_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "fwi_comm_abort": (C.c_int, [_P]),
     "fwi_last_loop_ms": (C.c_int, [_P, C.POINTER(_D)]),
     "fwi_synchronize": (C.c_int, [_P]),
     "fwi_kernel_name": (C.c_char_p, [_P]),

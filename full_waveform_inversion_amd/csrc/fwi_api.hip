@@ -93,6 +93,7 @@ struct fwi_ctx {
     // checkpointing (SURVEY s.8f-3): snapshot of (u^n, u^{n-1}) every `ckpt` steps instead of the
     // imaging term of every step; q_store then holds ckpt + 1 slots and fwd[] the recomputed fields
     int ckpt = 0;
+    bool ckpt_ready = false;  // every checkpoint buffer below is allocated
     void *snap = nullptr, *fwd[2] = {nullptr, nullptr};
     // 2-D temporal blocking: second buffer pair the fused kernel writes into, and whether it is used
     bool fused2d = false;
@@ -151,7 +152,11 @@ int upload_vec(fwi_ctx *ctx, void *dst, const std::vector<double> &v) {
 // tens of ms per 2 MB copy (measured in the 2-D shot loop).
 int stage_reserve(fwi_ctx *ctx, size_t bytes) {
     if (ctx->cap_pin >= bytes && ctx->pin) return FWI_OK;
-    if (ctx->pin) HIPCHK(ctx, hipHostFree(ctx->pin));
+    if (ctx->pin) {
+        // an H2D copy out of the buffer may still be queued on the stream (forward: the wavelet upload)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipHostFree(ctx->pin));
+    }
     ctx->pin = nullptr;
     HIPCHK(ctx, hipHostMalloc(&ctx->pin, bytes ? bytes : 16, hipHostMallocDefault));
     ctx->cap_pin = bytes;
@@ -633,19 +638,41 @@ struct Impl {
                                  bytes / 1073741824.0, ctx->cfg.nt_max, fr / 1073741824.0);
             HIPCHK(ctx, hipMalloc(&ctx->q_store, bytes));
         }
-        if (save && K > 0 && !ctx->snap) {
+        if (save && K > 0 && !ctx->ckpt_ready) {
+            // snapshots of (u^n, u^{n-1}) per segment, K + 1 imaging-term slots, the recomputation's field
+            // pair(s).  All or nothing: a partial set would let a later adjoint run on null buffers.
             const int nseg = (ctx->cfg.nt_max + K - 1) / K;
-            HIPCHK(ctx, hipMalloc(&ctx->snap, (size_t)nseg * 2 * g.ptot * sizeof(T)));
-            HIPCHK(ctx, hipMalloc(&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T)));  // K slots + carry
-            HIPCHK(ctx, hipMalloc(&ctx->fwd[0], (size_t)g.ptot * sizeof(T)));
-            HIPCHK(ctx, hipMalloc(&ctx->fwd[1], (size_t)g.ptot * sizeof(T)));
-            if (ctx->fused2d) {
-                HIPCHK(ctx, hipMalloc(&ctx->fwx[0], (size_t)g.ptot * sizeof(T)));
-                HIPCHK(ctx, hipMalloc(&ctx->fwx[1], (size_t)g.ptot * sizeof(T)));
-                HIPCHK(ctx, hipMemsetAsync(ctx->fwx[0], 0, (size_t)g.ptot * sizeof(T), ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(ctx->fwx[1], 0, (size_t)g.ptot * sizeof(T), ctx->stream));
+            const size_t fb = (size_t)g.ptot * sizeof(T);
+            struct { void **p; size_t bytes; bool zero; } want[] = {
+                {&ctx->snap, (size_t)nseg * 2 * fb, false},
+                {&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T), false},  // K slots + carry
+                {&ctx->fwd[0], fb, false}, {&ctx->fwd[1], fb, false},
+                {&ctx->fwx[0], ctx->fused2d ? fb : 0, true}, {&ctx->fwx[1], ctx->fused2d ? fb : 0, true}};
+            size_t total = 0, fr = 0, tot = 0;
+            for (auto &w : want) total += w.bytes;
+            HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
+            hipError_t e = hipSuccess;
+            if (total <= fr)
+                for (auto &w : want) {
+                    if (!w.bytes) continue;
+                    if ((e = hipMalloc(w.p, w.bytes)) != hipSuccess) break;
+                    if (w.zero && (e = hipMemsetAsync(*w.p, 0, w.bytes, ctx->stream)) != hipSuccess) break;
+                }
+            if (total > fr || e != hipSuccess) {
+                (void)hipGetLastError();
+                for (auto &w : want) {
+                    if (*w.p) (void)hipFree(*w.p);
+                    *w.p = nullptr;
+                }
+                return ctx->fail(FWI_ENOMEM,
+                                 "checkpoint buffers need %.1f GiB (nt_max=%d, ckpt_interval=%d) but only %.1f GiB "
+                                 "are free; a ckpt_interval near sqrt(2 nt_max) needs the least memory",
+                                 total / 1073741824.0, ctx->cfg.nt_max, K, fr / 1073741824.0);
             }
+            ctx->ckpt_ready = true;
         }
+        // the pinned staging buffer at its final size for this shot, before any copy is queued on it
+        if ((rc = stage_reserve(ctx, (size_t)nt * std::max(std::max(nsrc, nrec), 1) * sizeof(T)))) return rc;
         if ((rc = ensure(ctx, &ctx->wav, &ctx->cap_wav, (size_t)nt * std::max(nsrc, 1) * sizeof(T)))) return rc;
         if ((rc = ensure(ctx, &ctx->amp, &ctx->cap_amp, (size_t)nt * std::max(nrec, 1) * sizeof(T)))) return rc;
         if ((rc = ensure(ctx, &ctx->series, &ctx->cap_series,
@@ -1312,8 +1339,35 @@ int fwi_comm_init(fwi_ctx *ctx, int32_t rank, int32_t nranks, const void *id) {
     }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    NCCLCHK(ctx, ncclCommInitRank(&ctx->comm, nranks, uid, rank));
+    ncclResult_t r = ncclCommInitRank(&ctx->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        ctx->nranks = 1;
+        return ctx->fail(FWI_ECOMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
+    }
     ctx->nranks = nranks;
+    return FWI_OK;
+}
+
+int fwi_comm_info(fwi_ctx *ctx, int32_t *nranks_out, int32_t *rank_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->comm) return ctx->fail(FWI_ESTATE, "fwi_comm_info: call fwi_comm_init first");
+    int n = 0, r = -1;
+    NCCLCHK(ctx, ncclCommCount(ctx->comm, &n));
+    NCCLCHK(ctx, ncclCommUserRank(ctx->comm, &r));
+    if (nranks_out) *nranks_out = n;
+    if (rank_out) *rank_out = r;
+    return FWI_OK;
+}
+
+int fwi_comm_abort(fwi_ctx *ctx) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->comm) return FWI_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    ncclComm_t c = ctx->comm;
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    NCCLCHK(ctx, ncclCommAbort(c));
     return FWI_OK;
 }
 
@@ -1328,16 +1382,24 @@ int fwi_allreduce_gradient(fwi_ctx *ctx) {
     return FWI_OK;
 }
 
-int fwi_allreduce_f64(fwi_ctx *ctx, double *vals, int32_t n) {
+static int allreduce_scalars(fwi_ctx *ctx, double *vals, int32_t n, ncclRedOp_t op, const char *who) {
     if (!ctx) return FWI_EINVAL;
-    if (!ctx->comm) return ctx->fail(FWI_ESTATE, "fwi_allreduce_f64: call fwi_comm_init first");
-    if (!vals || n < 1 || n > 8) return ctx->fail(FWI_EINVAL, "fwi_allreduce_f64: n must be in [1, 8]");
+    if (!ctx->comm) return ctx->fail(FWI_ESTATE, "%s: call fwi_comm_init first", who);
+    if (!vals || n < 1 || n > 8) return ctx->fail(FWI_EINVAL, "%s: n must be in [1, 8]", who);
     (void)hipSetDevice(ctx->cfg.device);
     HIPCHK(ctx, hipMemcpyAsync(ctx->red, vals, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    NCCLCHK(ctx, ncclAllReduce(ctx->red, ctx->red, (size_t)n, ncclFloat64, ncclSum, ctx->comm, ctx->stream));
+    NCCLCHK(ctx, ncclAllReduce(ctx->red, ctx->red, (size_t)n, ncclFloat64, op, ctx->comm, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(vals, ctx->red, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FWI_OK;
+}
+
+int fwi_allreduce_f64(fwi_ctx *ctx, double *vals, int32_t n) {
+    return allreduce_scalars(ctx, vals, n, ncclSum, "fwi_allreduce_f64");
+}
+
+int fwi_allreduce_f64_max(fwi_ctx *ctx, double *vals, int32_t n) {
+    return allreduce_scalars(ctx, vals, n, ncclMax, "fwi_allreduce_f64_max");
 }
 
 int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out) {

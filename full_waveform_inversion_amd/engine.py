@@ -103,6 +103,15 @@ class Engine:
     def _chk(self, code):
         _lib.check(self._ctx, code)
 
+    @property
+    def _c(self):
+        """The context handle, or a clear error when it does not exist yet (with ``npml > 0`` and no
+        ``sigma_max`` the context is created by the first ``set_model``, which knows ``c_max``)."""
+        if self._ctx is None:
+            raise _lib.FwiError(3, "no context yet: call set_model() first (npml > 0 without sigma_max defers "
+                                   "fwi_create until the model's maximum velocity is known)")
+        return self._ctx
+
     def _host(self, a, shape=None):
         a = np.ascontiguousarray(a, dtype=self.dtype)
         if shape is not None and a.shape != tuple(shape):
@@ -180,7 +189,7 @@ class Engine:
         if a.size != b.size:
             raise ValueError("dot: size mismatch")
         out = C.c_double(0.0)
-        self._chk(self._lib.fwi_dot(self._ctx, a.ctypes.data_as(C.c_void_p),
+        self._chk(self._lib.fwi_dot(self._c, a.ctypes.data_as(C.c_void_p),
                                     b.ctypes.data_as(C.c_void_p), a.size, C.byref(out)))
         return out.value
 
@@ -193,60 +202,71 @@ class Engine:
     def comm_init(self, rank, nranks, unique_id):
         if len(unique_id) != _lib.UNIQUE_ID_BYTES:
             raise ValueError("unique id must be %d bytes" % _lib.UNIQUE_ID_BYTES)
-        self._chk(self._lib.fwi_comm_init(self._ctx, rank, nranks, C.c_char_p(unique_id)))
+        self._chk(self._lib.fwi_comm_init(self._c, rank, nranks, C.c_char_p(unique_id)))
 
     def allreduce_gradient(self):
-        self._chk(self._lib.fwi_allreduce_gradient(self._ctx))
+        self._chk(self._lib.fwi_allreduce_gradient(self._c))
 
-    def allreduce_f64(self, vals):
+    def allreduce_f64(self, vals, op="sum"):
         arr = (C.c_double * len(vals))(*vals)
-        self._chk(self._lib.fwi_allreduce_f64(self._ctx, arr, len(vals)))
+        fn = {"sum": self._lib.fwi_allreduce_f64, "max": self._lib.fwi_allreduce_f64_max}[op]
+        self._chk(fn(self._c, arr, len(vals)))
         return list(arr)
+
+    def comm_info(self):
+        """(nranks, rank) as RCCL reports them for this context's communicator."""
+        n, r = C.c_int32(0), C.c_int32(-1)
+        self._chk(self._lib.fwi_comm_info(self._c, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
+    def comm_abort(self):
+        if self._ctx is not None:
+            self._chk(self._lib.fwi_comm_abort(self._ctx))
 
     # -- device-resident model-shaped vectors (optimiser state) ------------------------
     def vec_create(self, count):
-        self._chk(self._lib.fwi_vec_create(self._ctx, int(count)))
+        self._chk(self._lib.fwi_vec_create(self._c, int(count)))
 
     def vec_upload(self, slot, a):
         a = self._host(a, self.shape)
-        self._chk(self._lib.fwi_vec_upload(self._ctx, slot, a.ctypes.data_as(C.c_void_p)))
+        self._chk(self._lib.fwi_vec_upload(self._c, slot, a.ctypes.data_as(C.c_void_p)))
 
     def vec_download(self, slot):
         out = np.empty(self.shape, self.dtype)
-        self._chk(self._lib.fwi_vec_download(self._ctx, slot, out.ctypes.data_as(C.c_void_p)))
+        self._chk(self._lib.fwi_vec_download(self._c, slot, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def vec_copy(self, dst, src):
-        self._chk(self._lib.fwi_vec_copy(self._ctx, dst, src))
+        self._chk(self._lib.fwi_vec_copy(self._c, dst, src))
 
     def vec_axpby(self, y, a, x, b=1.0):
         """y = a * x + b * y on the device."""
-        self._chk(self._lib.fwi_vec_axpby(self._ctx, y, float(a), x, float(b)))
+        self._chk(self._lib.fwi_vec_axpby(self._c, y, float(a), x, float(b)))
 
     def vec_dot(self, x, y):
         out = C.c_double(0.0)
-        self._chk(self._lib.fwi_vec_dot(self._ctx, x, y, C.byref(out)))
+        self._chk(self._lib.fwi_vec_dot(self._c, x, y, C.byref(out)))
         return out.value
 
     def vec_absmax(self, x):
         out = C.c_double(0.0)
-        self._chk(self._lib.fwi_vec_absmax(self._ctx, x, C.byref(out)))
+        self._chk(self._lib.fwi_vec_absmax(self._c, x, C.byref(out)))
         return out.value
 
     def vec_clip(self, x, lo, hi):
-        self._chk(self._lib.fwi_vec_clip(self._ctx, x, float(lo), float(hi)))
+        self._chk(self._lib.fwi_vec_clip(self._c, x, float(lo), float(hi)))
 
     def set_model_vec(self, slot):
-        self._chk(self._lib.fwi_set_model_vec(self._ctx, slot))
+        self._chk(self._lib.fwi_set_model_vec(self._c, slot))
 
     def gradient_vec(self, slot, wrt="velocity"):
         w = {"velocity": _lib.WRT_VELOCITY, "slowness2": _lib.WRT_SLOWNESS2}[wrt]
-        self._chk(self._lib.fwi_gradient_vec(self._ctx, w, slot))
+        self._chk(self._lib.fwi_gradient_vec(self._c, w, slot))
 
     def last_loop_ms(self):
         ms = C.c_double(0.0)
-        self._chk(self._lib.fwi_last_loop_ms(self._ctx, C.byref(ms)))
+        self._chk(self._lib.fwi_last_loop_ms(self._c, C.byref(ms)))
         return ms.value
 
     def synchronize(self):
-        self._chk(self._lib.fwi_synchronize(self._ctx))
+        self._chk(self._lib.fwi_synchronize(self._c))

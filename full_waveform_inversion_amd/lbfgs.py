@@ -18,6 +18,8 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
     for the GPU wave-shuffle reduction).  Returns ``(x, f, log)``.
     """
     dot = dot or (lambda a, b: float(np.sum(np.multiply(a, b, dtype=np.float64))))  # no BLAS threads
+    if int(history) < 1:
+        raise ValueError("history must be >= 1")
     lo, hi = bounds if bounds is not None else (None, None)
 
     def project(x):
@@ -25,6 +27,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
 
     x = project(np.array(x0, copy=True))
     f, g = fg(x)
+    _require_finite(f, float(np.abs(g).max()), dot(g, g), 0)
     S, Y, log = [], [], [{"iter": 0, "f": f, "evals": 1}]
     evals = 1
     for it in range(1, maxiter + 1):
@@ -70,10 +73,19 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
                 S.pop(0)
                 Y.pop(0)
         x, f, g = xn, fn, gn
+        _require_finite(f, float(np.abs(g).max()), dot(g, g), it)
         log.append({"iter": it, "f": f, "evals": evals, "step": t})
         if callback:
             callback(it, x, f, g)
     return x, f, log
+
+
+def _require_finite(f, gmax, gg, it):
+    """A blown-up propagation must not pass for convergence: ``max |g|`` built on ``fmax`` ignores NaN
+    (an all-NaN gradient reads 0 = "stationary"), so the squared norm is checked as well."""
+    if not (np.isfinite(f) and np.isfinite(gmax) and np.isfinite(gg)):
+        raise FloatingPointError("L-BFGS iteration %d: non-finite misfit or gradient (f=%r, max|g|=%r, g.g=%r); "
+                                 "check the time step against the CFL limit of the current model" % (it, f, gmax, gg))
 
 
 def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=None, c1=1e-4, max_ls=8,
@@ -86,15 +98,20 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
     with ``x`` downloaded once at the end.
     """
     m = int(history)
+    if m < 1:
+        raise ValueError("history must be >= 1")
     X, G, XN, GN, P = 0, 1, 2, 3, 4
-    S0, Y0 = 5, 5 + m
-    engine.vec_create(5 + 2 * m)
+    # m + 1 pair slots: the candidate pair is formed in a spare slot, so the oldest pair is evicted only
+    # once the candidate has passed the curvature test
+    S0, Y0 = 5, 5 + (m + 1)
+    engine.vec_create(5 + 2 * (m + 1))
     engine.vec_upload(X, x0)
     if bounds is not None:
         engine.vec_clip(X, *bounds)
     f = fg(X, G)
+    _require_finite(f, engine.vec_absmax(G), engine.vec_dot(G, G), 0)
     pairs = []  # ring of (s_slot, y_slot), oldest first
-    free = list(range(m))
+    free = list(range(m + 1))
     log = [{"iter": 0, "f": f, "evals": 1}]
     evals = 1
     for it in range(1, maxiter + 1):
@@ -137,10 +154,7 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
         else:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
             break
-        if not free:  # drop the oldest pair
-            s_old, _ = pairs.pop(0)
-            free.append(s_old - S0)
-        k = free.pop(0)
+        k = free.pop(0)  # never empty: at most m of the m + 1 slots hold history
         s, y = S0 + k, Y0 + k
         engine.vec_copy(s, XN)
         engine.vec_axpby(s, -1.0, X, 1.0)
@@ -149,11 +163,15 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
         sy = engine.vec_dot(s, y)
         if sy > 1e-12 * np.sqrt(engine.vec_dot(s, s) * engine.vec_dot(y, y)):
             pairs.append((s, y))
+            if len(pairs) > m:  # the new pair is good: now the oldest one goes
+                s_old, _ = pairs.pop(0)
+                free.append(s_old - S0)
         else:
             free.append(k)
         X, XN = XN, X
         G, GN = GN, G
         f = fn
+        _require_finite(f, engine.vec_absmax(G), engine.vec_dot(G, G), it)
         log.append({"iter": it, "f": f, "evals": evals, "step": t})
         if callback:
             callback(it, X, f, G)

@@ -64,14 +64,32 @@ class NoExchange:
 class RcclExchange:
     """Production exchange: RCCL all-reduce (over xGMI) of the device-side accumulators.
 
-    ``broadcast`` moves the 128-byte ncclUniqueId from rank 0 to everyone over whatever
-    control plane the launcher offers (bench.py uses torch.distributed/gloo for it).
+    ``rdzv`` (:class:`rendezvous.Rendezvous`, or anything with ``rank`` / ``world`` / ``broadcast`` /
+    ``allreduce``) is the control plane: it moves the 128-byte ncclUniqueId from rank 0 to everyone and
+    agrees on whether every rank's communicator came up.  A communicator that fails on ANY rank is fatal
+    on ALL of them (the ranks that succeeded abort theirs): there is no host-side fallback for the sum.
     """
 
-    def __init__(self, engine, rank, world, broadcast):
-        self.rank, self.world = rank, world
-        uid = type(engine).comm_unique_id() if rank == 0 else None
-        engine.comm_init(rank, world, broadcast(uid))
+    def __init__(self, engine, rdzv):
+        self.rank, self.world = rdzv.rank, rdzv.world
+        uid = rdzv.broadcast(type(engine).comm_unique_id() if self.rank == 0 else None)
+        err = ""
+        try:
+            engine.comm_init(self.rank, self.world, uid)
+            seen = engine.comm_info()
+            if seen != (self.world, self.rank):
+                err = "RCCL reports rank %d of %d, expected %d of %d" % (seen[1], seen[0], self.rank, self.world)
+        except Exception as ex:  # FwiError: reported to every rank below, then raised
+            err = str(ex)
+        ok = rdzv.allreduce([0.0 if err else 1.0], "min")[0] == 1.0
+        if not ok:
+            try:
+                engine.comm_abort()
+            except Exception:
+                pass
+            raise RuntimeError("RCCL communicator did not come up on every rank"
+                               + (" (this rank: %s)" % err if err else " (failed on another rank)"))
+        self.rccl_ranks = seen[0]
 
     def reduce(self, engine, misfit, wrt):
         engine.allreduce_gradient()
@@ -84,21 +102,17 @@ class RcclExchange:
 
 
 class HostExchange:
-    """Sum on host arrays through a torch.distributed process group (gloo): the path the
-    CPU-only multi-process tests exercise; same sharding and reduction semantics."""
+    """Sum on host arrays over the control plane (:class:`rendezvous.Rendezvous`): the path the CPU-only
+    multi-process tests exercise with the oracle-backed engine; same sharding and reduction semantics as
+    :class:`RcclExchange`.  Not a fallback of it -- nothing in the product path constructs this."""
 
-    def __init__(self, dist):
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+    def __init__(self, rdzv):
+        self.rdzv = rdzv
+        self.rank, self.world = rdzv.rank, rdzv.world
 
     def reduce(self, engine, misfit, wrt):
-        import torch
-        g = np.ascontiguousarray(engine.gradient(wrt))
-        tg = torch.from_numpy(g)
-        self.dist.all_reduce(tg)
-        tj = torch.tensor([misfit], dtype=torch.float64)
-        self.dist.all_reduce(tj)
-        return g, float(tj[0])
+        g = self.rdzv.allreduce_array(engine.gradient(wrt))
+        return g, self.rdzv.allreduce([misfit])[0]
 
 
 class EnginePool:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 8
+#define FWI_ABI_VERSION 9
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -155,9 +155,16 @@ int fwi_gradient_vec(fwi_ctx *ctx, int32_t wrt, int32_t slot);
 #define FWI_UNIQUE_ID_BYTES 128
 int fwi_comm_unique_id(void *id_out /* FWI_UNIQUE_ID_BYTES */);
 int fwi_comm_init(fwi_ctx *ctx, int32_t rank, int32_t nranks, const void *id);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the evidence that
+ * the N ranks of a job really share one communicator, echoed by bench.py as config.rccl_ranks. */
+int fwi_comm_info(fwi_ctx *ctx, int32_t *nranks_out, int32_t *rank_out);
+/* Tear the communicator down without waiting for peers (ncclCommAbort): the clean-up of a rank whose
+ * job is being abandoned because another rank failed to join. */
+int fwi_comm_abort(fwi_ctx *ctx);
 int fwi_allreduce_gradient(fwi_ctx *ctx);
-/* In-place sum over ranks of n doubles (misfit values etc.). */
+/* In-place sum / max over ranks of n <= 8 doubles (misfit values; the slowest rank's elapsed time). */
 int fwi_allreduce_f64(fwi_ctx *ctx, double *vals, int32_t n);
+int fwi_allreduce_f64_max(fwi_ctx *ctx, double *vals, int32_t n);
 
 /* Measurement hooks (bench.py): device time of the last time loop, from HIP
  * events on the context's stream, and the synchronising fence. */

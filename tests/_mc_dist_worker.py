@@ -1,16 +1,15 @@
 """Rank body of the world_size-2 Monte Carlo sharding test.  ``backend`` = "oracle": the device call is
-replaced by the CPU oracle (CPU suite, gloo); "gpu": the real fwi_mc_invert on device 0 (GPU suite)."""
+replaced by the CPU oracle (CPU suite); "gpu": the real fwi_mc_invert on device 0 (GPU suite)."""
 import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from full_waveform_inversion_amd import samplers, source_inversion as si  # noqa: E402
+from full_waveform_inversion_amd.rendezvous import Rendezvous  # noqa: E402
 from oracle import mc_oracle as mo  # noqa: E402
 
 
@@ -33,23 +32,21 @@ def problem():
 
 def main():
     out, backend = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rdzv = Rendezvous.from_env(timeout=120)
+    rank, world = rdzv.rank, rdzv.world
     if backend == "oracle":
         si.invert_on_device = oracle_invert
 
     def sum_over_ranks(x):
-        tns = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(tns)
-        return float(tns[0])
+        return rdzv.allreduce([x])[0]
 
     d, G, N, typ = problem()
     first, M, post, like = si.perform_monte_carlo_sampled_waveform_inversion_sharded(
         d, G, N, rank, world, sum_over_ranks, M_amplitude=1.5, inversion_type=typ, comparison_metric="VR",
         perform_normallised_waveform_inversion=False, compare_all_waveforms_simultaneously=False, seed=9)
     np.savez(out + ".rank%d.npz" % rank, first=first, M=M, post=post, like=like)
-    dist.barrier()
-    dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """Tests-only stand-in with the Engine interface, backed by the CPU oracle.
 
-Lets the CPU multi-process (gloo) tests drive the real shot-sharding / exchange /
+Lets the CPU multi-process tests drive the real shot-sharding / exchange /
 optimiser host code without a GPU.  Never imported by the product package.
 """
 import numpy as np

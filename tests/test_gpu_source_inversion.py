@@ -169,7 +169,7 @@ def test_invert_on_device_equals_sample_then_score(gpu, typ):
 
 
 def test_two_ranks_share_one_run(gpu, tmp_path):
-    """Two processes on this GPU (sample-index blocks + one scalar all-reduce over gloo) reproduce the
+    """Two processes on this GPU (sample-index blocks + one scalar all-reduce over the stdlib control plane) reproduce the
     single-process device run bit for bit."""
     import sys
     sys.path.insert(0, os.path.dirname(__file__))

@@ -1,4 +1,5 @@
-"""Host-side logic on CPU: workloads, shot sharding, exchange over gloo (world_size 2), L-BFGS."""
+"""Host-side logic on CPU: workloads, shot sharding, the stdlib control plane and the exchange over it
+(world_size 2 and 3, also under torch.distributed.run), L-BFGS."""
 import os
 import socket
 import subprocess
@@ -54,22 +55,87 @@ def _serial_reference():
     return sh.misfit_and_gradient(e, w.c_init, shots)
 
 
-def test_shot_parallel_gloo_world2_matches_serial(tmp_path):
-    """Two processes, 5 shots split 3 + 2, gradient and misfit summed over gloo == serial."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    out = str(tmp_path / "res")
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(script, args, world, port=None, extra_env=None):
+    port = port or _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), out],
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", script)] + list(args),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
     for p in procs:
         o, _ = p.communicate(timeout=300)
-        assert p.returncode == 0, o.decode()[-2000:]
+        outs.append((p.returncode, o.decode()[-2000:]))
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_control_plane_collectives(tmp_path, world):
+    """broadcast / barrier / allreduce (sum, max, min) / array sum / gather of the stdlib rendezvous."""
+    out = str(tmp_path / "rdzv")
+    for rc, o in _spawn_ranks("_rdzv_worker.py", [out], world):
+        assert rc == 0, o
+    assert all(os.path.exists("%s.rank%d" % (out, r)) for r in range(world))
+
+
+def test_control_plane_under_torch_distributed_run(tmp_path):
+    """The driver launches bench.py with `python -m torch.distributed.run`: its agent owns MASTER_PORT, the ranks
+    must still find each other (ports MASTER_PORT + 1 ...), and no rank imports torch."""
+    out = str(tmp_path / "rdzv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rdzv_worker.py"), out]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert open(out + ".rank0").read() == "ok 0 2" and open(out + ".rank1").read() == "ok 1 2"
+
+
+def test_control_plane_skips_a_foreign_listener_and_times_out_alone():
+    """A rank 0 of ANOTHER job (different MASTER_PORT token) on a neighbouring port is not joined; a rank whose
+    rank 0 never appears gives up with an error instead of hanging."""
+    import threading
+    from full_waveform_inversion_amd.rendezvous import Rendezvous, RendezvousError
+    port = _free_port()
+    res = {}
+
+    def other_job():  # listens on port + 2 (its own MASTER_PORT is port + 1), waits for a peer that never comes
+        try:
+            Rendezvous(0, 2, "127.0.0.1", port + 1, timeout=3.0)
+        except RendezvousError as ex:
+            res["other"] = str(ex)
+
+    t = threading.Thread(target=other_job)
+    t.start()
+    with pytest.raises(RendezvousError, match="found no rank 0"):
+        Rendezvous(1, 2, "127.0.0.1", port, timeout=1.5)  # probes port + 1 .. : meets the other job, is refused
+    t.join()
+    assert "only 1 of 2 ranks joined" in res["other"]
+    with pytest.raises(ValueError):
+        Rendezvous(2, 2)
+
+
+def test_no_torch_on_the_product_and_bench_path():
+    """north_star: "host code stays in Python calling HIP through a thin ctypes C-ABI shim (no PyTorch)"."""
+    import re
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "tools", "run_config.py")]
+    for dirpath, _, fs in os.walk(os.path.join(ROOT, "full_waveform_inversion_amd")):
+        files += [os.path.join(dirpath, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        assert not re.search(r"^\s*(import|from)\s+torch\b", open(f).read(), re.M), f
+
+
+def test_shot_parallel_world2_matches_serial(tmp_path):
+    """Two processes, 5 shots split 3 + 2, gradient and misfit summed over the control plane == serial."""
+    out = str(tmp_path / "res")
+    for rc, o in _spawn_ranks("_dist_worker.py", [out], 2):
+        assert rc == 0, o
     J, g = _serial_reference()
     res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
     assert list(res[0]["mine"]) == [0, 2, 4] and list(res[1]["mine"]) == [1, 3]
@@ -79,24 +145,13 @@ def test_shot_parallel_gloo_world2_matches_serial(tmp_path):
 
 
 def _run_mc_world2(tmp_path, backend):
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     out = str(tmp_path / "mc")
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_mc_dist_worker.py"), out,
-                                       backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        o, _ = p.communicate(timeout=300)
-        assert p.returncode == 0, o.decode()[-2000:]
+    for rc, o in _spawn_ranks("_mc_dist_worker.py", [out, backend], 2):
+        assert rc == 0, o
     return [np.load(out + ".rank%d.npz" % r) for r in range(2)]
 
 
-def test_monte_carlo_sample_sharding_world2_gloo(tmp_path):
+def test_monte_carlo_sample_sharding_world2(tmp_path):
     """Sample-index sharding of the Monte Carlo loop (the reference's process fan-out, :816-848): two
     ranks' blocks together are the single-rank run, and the one exchanged scalar normalises the posterior
     over all samples.  The device call is replaced by the oracle here (no GPU in this suite)."""

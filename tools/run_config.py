@@ -48,17 +48,16 @@ def main():
                                         sigma_max=sigma, image_stride=a.image_stride), psize)
     e = pool.primary
     ex = sh.NoExchange()
-    dist = None
+    rdzv = None
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # control plane: the package's stdlib rendezvous on MASTER_ADDR / MASTER_PORT (no torch in this process)
+        from full_waveform_inversion_amd.rendezvous import Rendezvous
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        rdzv = Rendezvous.from_env()
         e.set_model(w.c.astype(np.float32))
-
-        def bcast(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        ex = sh.RcclExchange(e, rank, world, bcast)
+        ex = sh.RcclExchange(e, rdzv)  # raises on every rank if any rank's communicator fails
     sh.model_data(pool, w.c.astype(np.float32), shots, ex)
     t0 = time.perf_counter()
     evals = [0]
@@ -89,8 +88,9 @@ def main():
                           "Gpts_per_s_fwd_plus_adj": round(upd / el / 1e9, 2), "kernel": e.kernel_name,
                           "log": log}))
     pool.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":
