@@ -49,6 +49,7 @@ SIGNATURES = {
     "fwi_set_model": (C.c_int, [_P, _P]),
     "fwi_forward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _I32, _P]),
     "fwi_adjoint": (C.c_int, [_P, _P, _I32, _P]),
+    "fwi_misfit_l2": (C.c_int, [_P, _P, C.POINTER(_D)]),
     "fwi_gradient": (C.c_int, [_P, _I32, _P]),
     "fwi_gradient_reset": (C.c_int, [_P]),
     "fwi_gradient_add": (C.c_int, [_P, _P]),

@@ -68,6 +68,7 @@ struct fwi_ctx {
     // per-shot point sets (device) and their sizes
     int nt = 0, nsrc = 0, nrec = 0;
     bool have_forward = false, have_q = false;
+    bool have_dev_residual = false;  // ctx->amp holds the residual fwi_misfit_l2 formed on the device
     // A point set on the device: original order (sampling, POINT-kernel injection) and the
     // copy sorted by stream-kernel tile with its CSR offsets (fused injection).
     struct PointSet {
@@ -683,6 +684,7 @@ struct Impl {
         ctx->nrec = nrec;
         ctx->have_forward = false;
         ctx->have_q = false;
+        ctx->have_dev_residual = false;
         hipStream_t s = ctx->stream;
         if (nsrc && (rc = upload_series(ctx, ctx->wav, wavelet, (size_t)nt * nsrc * sizeof(T)))) return rc;
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
@@ -752,8 +754,9 @@ struct Impl {
         const int nt = ctx->nt, K = ctx->ckpt;
         hipStream_t s = ctx->stream;
         int rc;
-        if (ctx->nrec && (rc = upload_series(ctx, ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T))))
-            return rc;
+        if (ctx->nrec && residual && (rc = upload_series(ctx, ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T))))
+            return rc;  // (residual == nullptr: the one fwi_misfit_l2 left in ctx->amp)
+        ctx->have_dev_residual = false;  // consumed: ctx->series is about to be overwritten
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
         Sweep sw;
@@ -901,6 +904,23 @@ struct Impl {
         const double scale = -(double)ctx->istride / (ctx->cfg.dt * ctx->cfg.dt);  // istride: quadrature weight
         HIPCHK(ctx, launch_finalize_gradient<T>(ctx->gd, (const T *)ctx->g_acc, (const T *)ctx->c_dev, (T *)dev, scale,
                                                 wrt == FWI_WRT_VELOCITY, ctx->stream));
+        return FWI_OK;
+    }
+
+    // d_obs -> ctx->amp, then amp := series - amp and J = 1/2 sum amp^2, all on the device
+    static int misfit_l2(fwi_ctx *ctx, const T *d_obs, double *J_out) {
+        const size_t n = (size_t)ctx->nt * ctx->nrec;
+        double ss = 0.0;
+        if (n) {
+            int rc = upload_series(ctx, ctx->amp, d_obs, n * sizeof(T));
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemsetAsync(ctx->red, 0, sizeof(double), ctx->stream));
+            HIPCHK(ctx, launch_residual_l2<T>((const T *)ctx->series, (T *)ctx->amp, (int64_t)n, ctx->red, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&ss, ctx->red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        *J_out = 0.5 * ss;
+        ctx->have_dev_residual = true;
         return FWI_OK;
     }
 
@@ -1161,10 +1181,20 @@ int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src
     if (!ctx->have_forward) return ctx->fail(FWI_ESTATE, "fwi_adjoint: no forward run to adjoin");
     if (image && !ctx->have_q)
         return ctx->fail(FWI_ESTATE, "fwi_adjoint: imaging needs fwi_forward(save=1) first");
-    if (ctx->nrec && !residual) return ctx->fail(FWI_EINVAL, "fwi_adjoint: null residual");
+    if (ctx->nrec && !residual && !ctx->have_dev_residual)
+        return ctx->fail(FWI_EINVAL, "fwi_adjoint: null residual (and no fwi_misfit_l2 residual on the device)");
     (void)hipSetDevice(ctx->cfg.device);
     return DISPATCH(ctx, Impl<float>::adjoint(ctx, (const float *)residual, image, (float *)adj_src_out),
                     Impl<double>::adjoint(ctx, (const double *)residual, image, (double *)adj_src_out));
+}
+
+int fwi_misfit_l2(fwi_ctx *ctx, const void *d_obs, double *J_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->have_forward) return ctx->fail(FWI_ESTATE, "fwi_misfit_l2: no forward run whose data to compare");
+    if (!J_out || (ctx->nrec && !d_obs)) return ctx->fail(FWI_EINVAL, "fwi_misfit_l2: null argument");
+    (void)hipSetDevice(ctx->cfg.device);
+    return DISPATCH(ctx, Impl<float>::misfit_l2(ctx, (const float *)d_obs, J_out),
+                    Impl<double>::misfit_l2(ctx, (const double *)d_obs, J_out));
 }
 
 int fwi_gradient(fwi_ctx *ctx, int32_t wrt, void *g_out) {

@@ -110,6 +110,10 @@ hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);
 
+// obs_inout := syn - obs_inout; *out += sum of its squares (out zeroed by the caller)
+template <typename T>
+hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out, hipStream_t s);
+
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch
 constexpr int FUSED2D_TILE = 64;   // interior tile edge (points); extended edge = TILE + 2 STEPS r

@@ -910,6 +910,33 @@ hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_
     return hipGetLastError();
 }
 
+// Least-squares residual and misfit on the device: r = syn - obs (written over obs, where the adjoint
+// sweep reads its injection amplitudes), *out += sum r^2 -- same reduction shape as dot_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void residual_l2_kernel(const T *syn, T *obs_inout, int64_t n, double *out) {
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T r = syn[i] - obs_inout[i];
+        obs_inout[i] = r;
+        acc += (double)r * (double)r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+template <typename T>
+hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256));
+    hipLaunchKernelGGL(residual_l2_kernel<T>, dim3(blocks), dim3(256), 0, s, syn, obs_inout, n, out);
+    return hipGetLastError();
+}
+
 // Model-sized vector algebra for the optimiser (device-resident L-BFGS state).
 template <typename T>
 __global__ void axpby_kernel(T *y, double a, const T *x, double b, int64_t n) {
@@ -966,6 +993,7 @@ hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
                                                     hipStream_t);                                  \
     template hipError_t launch_repack<T>(const GridDesc &, T *, const T *, int, hipStream_t);       \
     template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
+    template hipError_t launch_residual_l2<T>(const T *, T *, int64_t, double *, hipStream_t);       \
     template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t); \
     template hipError_t launch_axpby<T>(T *, double, const T *, double, int64_t, hipStream_t);         \
     template hipError_t launch_clip<T>(const GridDesc &, T *, double, double, hipStream_t);           \

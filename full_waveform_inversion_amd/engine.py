@@ -158,14 +158,25 @@ class Engine:
         return seis
 
     def adjoint(self, residual, image=True):
-        """Back-propagate ``residual (nt, nrec)``; returns ``F^T residual`` as ``(nt, nsrc)``."""
+        """Back-propagate ``residual (nt, nrec)``; returns ``F^T residual`` as ``(nt, nsrc)``.
+        ``residual=None``: the residual :meth:`misfit_l2` formed on the device."""
         if self._ctx is None:
             raise _lib.FwiError(3, "adjoint: no forward run to adjoin")
-        residual = self._host(residual, (self._nt, self._nrec))
+        rp = None
+        if residual is not None:
+            residual = self._host(residual, (self._nt, self._nrec))
+            rp = residual.ctypes.data_as(C.c_void_p)
         out = np.zeros((self._nt, self._nsrc), self.dtype)
-        self._chk(self._lib.fwi_adjoint(self._ctx, residual.ctypes.data_as(C.c_void_p),
-                                        int(bool(image)), out.ctypes.data_as(C.c_void_p)))
+        self._chk(self._lib.fwi_adjoint(self._ctx, rp, int(bool(image)), out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def misfit_l2(self, d_obs):
+        """``J = 1/2 ||d_syn - d_obs||^2`` for the last forward's seismograms, residual formed and reduced on
+        the device and kept there for ``adjoint(None)``."""
+        d_obs = self._host(d_obs, (self._nt, self._nrec))
+        J = C.c_double(0.0)
+        self._chk(self._lib.fwi_misfit_l2(self._c, d_obs.ctypes.data_as(C.c_void_p), C.byref(J)))
+        return J.value
 
     def gradient(self, wrt="velocity"):
         if self._ctx is None:

@@ -210,11 +210,18 @@ def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", obj
 def _sweep_shots(engine, shots, ex, objective):
     """forward + adjoint of this rank's shots; returns the misfit, gradients summed into the
     (primary) engine's accumulator."""
+    from .objectives import l2
+
     def one(e, i):
         s = shots[i]
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
         d = s.forward(e, save=True)
+        if objective is l2 and s.rec_spread is None and hasattr(e, "misfit_l2"):
+            # least squares on node receivers: residual and misfit are formed on the device
+            j = e.misfit_l2(s.d_obs)
+            e.adjoint(None)
+            return j
         j, r = objective(d, s.d_obs)
         s.adjoint(e, r)
         return j

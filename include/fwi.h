@@ -112,10 +112,17 @@ int fwi_forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx,
 
 /* adjoint(residual): reverse-time propagation of residual (nt, nrec) injected
  * at the receivers of the last forward.  image != 0 accumulates the zero-lag
- * forward x adjoint correlation into the gradient accumulator.  adj_src_out,
+ * forward x adjoint correlation into the gradient accumulator.  residual == NULL
+ * back-propagates the residual fwi_misfit_l2() left on the device.  adj_src_out,
  * if not NULL, receives F^T residual as (nt, nsrc).
  * [SURVEY s.8(a-1) rows adjoint / imaging condition] */
 int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src_out);
+
+/* Least-squares misfit on the device: with d_syn the seismograms of the last fwi_forward (still resident),
+ * forms the residual r = d_syn - d_obs there, returns J = 1/2 sum r^2 (wave64 __shfl_down reduction, fp64
+ * accumulate) and keeps r as the residual of the next fwi_adjoint(ctx, NULL, ...): neither the residual nor a
+ * second copy of the data crosses PCIe.  [SURVEY s.8(a-1) row "gradient dot-products / J"] */
+int fwi_misfit_l2(fwi_ctx *ctx, const void *d_obs /* (nt, nrec) */, double *J_out);
 
 /* gradient(): copy out the accumulated gradient, model-shaped, as dJ/dc
  * (FWI_WRT_VELOCITY) or dJ/d(1/c^2) (FWI_WRT_SLOWNESS2).

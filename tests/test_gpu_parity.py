@@ -401,6 +401,30 @@ def test_shot_loop_gradient_vs_oracle(gpu):
     assert rel(g1, g0) < TOL32 * amp
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_device_residual_and_misfit_equal_the_host_ones(gpu, dtype):
+    """fwi_misfit_l2: residual formed and reduced on the device (wave-shuffle reduction), back-propagated
+    by adjoint(None) -- the same residual bit for bit as d_syn - d_obs on the host, hence the same gradient."""
+    from full_waveform_inversion_amd import objectives as ob, shots as sh
+    w = workloads.cfg5(0.125, nshots=4)
+    wav = w.wavelet(np.dtype(dtype).type)
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(3)]
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, dtype=dtype) as e:
+        sh.model_data(e, w.c, shots)
+        J_dev, g_dev = sh.misfit_and_gradient(e, w.c_init, shots)                       # device residual
+        J_host, g_host = sh.misfit_and_gradient(e, w.c_init, shots, objective=lambda s, d: ob.l2(s, d))
+        assert abs(J_dev - J_host) <= 1e-12 * J_host and np.array_equal(g_dev, g_host)
+        d = e.forward(None, (w.src_idx[:1], wav), w.rec_idx, save=False)
+        assert abs(e.misfit_l2(np.zeros_like(d)) - 0.5 * float(np.sum(d.astype(np.float64) ** 2))) <= 1e-12 * np.sum(d ** 2)
+        e.adjoint(None, image=False)                # consumes the device residual
+        with pytest.raises(FwiError) as ei:         # ... so a second adjoint(None) has nothing to propagate
+            e.adjoint(None, image=False)
+        assert ei.value.code == 1
+        e.forward(None, (w.src_idx[:1], wav), w.rec_idx, save=False)
+        with pytest.raises(FwiError):               # a new forward invalidates the old residual too
+            e.adjoint(None, image=False)
+
+
 def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
     """cfg5 scaled (3-D, smooth random model): 3 L-BFGS iterations with the GPU dot product."""
     from full_waveform_inversion_amd import shots as sh

@@ -23,7 +23,9 @@ def _pair(seed=0, nt=120, k=5):
 
 
 @pytest.mark.parametrize("name,kw", [("l2", {}), ("VR", {"per_trace": True}), ("VR", {"per_trace": False}),
-                                     ("CC", {"per_trace": True}), ("CC", {"per_trace": False})])
+                                     ("CC", {"per_trace": True}), ("CC", {"per_trace": False}),
+                                     ("CC-shift", {"per_trace": True}), ("CC-shift", {"per_trace": False}),
+                                     ("gau", {"per_trace": True}), ("gau", {"per_trace": False})])
 def test_adjoint_source_is_the_derivative(name, kw):
     s, o = _pair()
     f = ob.OBJECTIVES[name]
@@ -45,6 +47,13 @@ def test_misfits_are_one_minus_the_reference_similarities():
                    (1 - mo.compare_synth_to_real_waveforms(real, synth, "PCC", False, allat))) < 1e-12
         assert abs(ob.correlation(s, o, per_trace=not allat)[0] -
                    (1 - mo.compare_synth_to_real_waveforms(real, synth, "CC", False, allat))) < 1e-12
+        assert abs(ob.correlation_shift(s, o, per_trace=not allat)[0] -
+                   (1 - mo.compare_synth_to_real_waveforms(real, synth, "CC-shift", False, allat))) < 1e-12
+    # gau: the reference's working branch is all-at-once (its per-trace branch returns 0, Appendix A-5);
+    # the misfit is -ln of that similarity.  Scaled so that exp() does not underflow.
+    s2 = o + 0.002 * (s - o)
+    gau = mo.compare_synth_to_real_waveforms(o.T, s2.T, "gau", False, True)
+    assert 0.0 < gau < 1.0 and abs(np.exp(-ob.gaussian(s2, o, per_trace=False)[0]) - gau) < 1e-12 * gau
 
 
 @pytest.mark.parametrize("name", ["VR", "CC"])
