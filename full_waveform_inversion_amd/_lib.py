@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfwi_hip.so")
+# FWI_HIP_LIB: load another build of the same library (the stamped diagnostic variant, `make stamps`)
+LIB_PATH = os.environ.get("FWI_HIP_LIB") or os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 9

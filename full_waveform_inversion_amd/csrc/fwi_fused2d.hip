@@ -16,6 +16,7 @@
 // No reference counterpart; arithmetic identical to step2d_tile / the oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "fwi_kernels.h"
@@ -35,6 +36,20 @@ __device__ __forceinline__ float rcp1(float a) {
 }
 
 }  // namespace
+
+// Diagnostic build only (make STAMPS=1 -> libfwi_hip_stamps.so, tools/stamp_fused2d.py): s_memtime at the phase
+// boundaries of every workgroup, into a buffer nothing else reads.  The production library holds none of this.
+#ifdef FWI_FUSED2D_STAMPS
+__device__ unsigned long long fwi_fused2d_stamps[4096 * 8];
+#define FWI_STAMP(k)                                                                                   \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                                     \
+            fwi_fused2d_stamps[blockIdx.x * 8 + (k)] = (k) == 7 ? __builtin_amdgcn_s_memrealtime()     \
+                                                                : __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define FWI_STAMP(k) do { } while (0)
+#endif
 
 // Tile geometry: interior FT x FT points, KS fused steps, radius R  ->  extended edge FT + 2 HL.
 // One workgroup per CU (the three LDS images take 111 KB).
@@ -65,47 +80,62 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
     __shared__ q4 fa[E][E4];             // field A (starts as u^n)
     __shared__ q4 fb[E][E4];             // field B (starts as u^{n-1})
     __shared__ q4 fc[E][E4];             // C = dt^2 c^2, 0 outside the grid
-    __shared__ float dzs[E], dxs[E];     // damping profiles of the tile's rows / columns
+    __shared__ float dzs[E];             // damping profiles of the tile's rows ...
+    __shared__ q4 dxs4[E4];              // ... and columns (read one 16-byte group at a time: conflict-free)
 
     const int tid = threadIdx.x;
+    FWI_STAMP(0);
     const int ntx = (g.nx + FT - 1) / FT;
-    const int tz = blockIdx.x / ntx, tx = blockIdx.x % ntx;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), each with a private L2.  Give
+    // every XCD a contiguous run of tiles (row-major: whole tile rows at 1024^2), so that the halo a tile shares
+    // with its neighbours -- 1.25 of the 2.25 tile areas each workgroup fetches -- is served by that L2 instead
+    // of crossing the fabric once per tile (the fill phase is fabric-bound: 6.5k of the workgroup's 23.6k cycles
+    // in the stamped build before, 4.5k after; 3.39 -> 2.69 us/step at 1024^2; tools/stamp_fused2d.py).  FWI_FUSED2D_NOREMAP (tuning hook): a.xcd_remap = 0.
+    int tile = blockIdx.x;
+    if (a.xcd_remap) {
+        const int nblk = gridDim.x, x = tile & 7, q = nblk >> 3, r = nblk & 7;  // the first r XCDs hold q + 1 tiles
+        tile = x * q + min(x, r) + (tile >> 3);
+    }
+    // (walking 4 x 4 blocks of tiles inside the run, so that an XCD owns a 4 x 8 patch instead of a 2 x 16 strip,
+    // was measured and rejected: 2.83 vs 2.69 us/step)
+    const int tz = tile / ntx, tx = tile % ntx;
     const int z0 = tz * FT - HL, x0 = tx * FT - HL;  // grid coordinates of extended (0, 0)
 
     // ---- load: zero outside the grid.  x0 and the 4-cell pad are multiples of 4, so a group is either left of
     // the grid, or starts inside it (a group straddling the right edge reads the pad: u = 0, C = 0 there) ------
     {
-        // Branch-free, all loads in flight before the first LDS write (a divergent `if`, or a select on the
-        // loaded value, made hipcc wait per group: 43 instead of 15 us per launch).  Groups outside the grid
-        // are pointed at the zero halo of the padded arrays -- row -1 / row nz, column -4 / the pad right of
-        // nx -- which holds exactly the zeros (u and C alike) they must see.
+        // LDS-DMA (global_load_lds_dwordx4): each wave-instruction moves 64 consecutive groups = 1 KiB straight
+        // into the (unpadded, group-ordered) LDS image -- destination = wave-uniform base + lane x 16 B, source
+        // address per lane -- so the tile never passes through VGPRs: no 27 x ds_write_b128 per thread (13
+        // issue cycles each, a third of this kernel's LDS-array cycles in the PMC pass of the register-staged
+        // form) and no 108 staging registers.  Branch-free per lane: groups outside the grid are pointed at the
+        // zero halo of the padded arrays -- row -1 / row nz, column -4 / the pad right of nx -- which holds
+        // exactly the zeros (u and C alike) they must see.
+        typedef __attribute__((address_space(1))) const void gptr_t;
+        typedef __attribute__((address_space(3))) void lptr_t;
         constexpr int GPT = (NG + FNT - 1) / FNT;
-        q4 va[GPT], vb[GPT], vc[GPT];
         const int xpad = (g.nx + 3) & ~3;
+        const int wave0 = tid & ~63;  // first thread of this wave
 #pragma unroll
         for (int i = 0; i < GPT; ++i) {
-            const int gi = min(tid + i * FNT, NG - 1);
-            const int lz = gi / E4, l4 = gi % E4;
-            const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
-            const int64_t p = g.off0 + (int64_t)zc * g.sz + xc;
-            va[i] = *reinterpret_cast<const q4 *>(a.u_cur + p);
-            vb[i] = *reinterpret_cast<const q4 *>(a.u_prev + p);
-            vc[i] = *reinterpret_cast<const q4 *>(a.C + p);
-        }
-#pragma unroll
-        for (int i = 0; i < GPT; ++i) {
+            const int g0 = wave0 + i * FNT;  // first group of this wave-instruction (wave-uniform)
+            if (g0 >= NG) break;
             const int gi = tid + i * FNT;
-            if (gi >= NG) break;
-            fa[gi / E4][gi % E4] = va[i];
-            fb[gi / E4][gi % E4] = vb[i];
-            fc[gi / E4][gi % E4] = vc[i];
+            if (gi < NG) {  // (only an image whose size is not a multiple of 64 groups has a partial last wave)
+                const int lz = gi / E4, l4 = gi % E4;
+                const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
+                const int64_t p = g.off0 + (int64_t)zc * g.sz + xc;
+                __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_cur + p), (lptr_t *)(&fa[0][0] + g0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_prev + p), (lptr_t *)(&fb[0][0] + g0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t *)(a.C + p), (lptr_t *)(&fc[0][0] + g0), 16, 0, 0);
+            }
         }
     }
     if (DAMP) {
         for (int i = tid; i < E; i += FNT) {
             const int z = z0 + i, x = x0 + i;
             dzs[i] = (z >= 0 && z < g.nz) ? a.dz[z] : 0.f;
-            dxs[i] = (x >= 0 && x < g.nx) ? a.dx[x] : 0.f;
+            dxs4[i >> 2].v[i & 3] = (x >= 0 && x < g.nx) ? a.dx[x] : 0.f;
         }
     }
     // fixed map of the interior (imaging accumulators, q prefetch, final stores): group ii = tid + i FNT
@@ -115,11 +145,12 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
         for (int i = 0; i < IPT; ++i) gacc[i] = {{0.f, 0.f, 0.f, 0.f}};
     }
     __syncthreads();
+    FWI_STAMP(1);
 
     q4(*cur)[E4] = fa;
     q4(*prv)[E4] = fb;
-    const int s0 = a.inj_start ? a.inj_start[blockIdx.x] : 0, s1 = a.inj_start ? a.inj_start[blockIdx.x + 1] : 0;
-    const int r0 = a.rec_start ? a.rec_start[blockIdx.x] : 0, r1 = a.rec_start ? a.rec_start[blockIdx.x + 1] : 0;
+    const int s0 = a.inj_start ? a.inj_start[tile] : 0, s1 = a.inj_start ? a.inj_start[tile + 1] : 0;
+    const int r0 = a.rec_start ? a.rec_start[tile] : 0, r1 = a.rec_start ? a.rec_start[tile + 1] : 0;
 
     auto substep = [&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
@@ -173,12 +204,13 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
                 }
             }
             const q4 up = prv[lz][l4], Cc = fc[lz][l4];
-            q4 q, un;
+            q4 q, un, dxv;
+            if (DAMP) dxv = dxs4[l4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 q.v[j] = Cc.v[j] * lap.v[j];
                 if (DAMP) {
-                    const float d = dzs[lz] + dxs[4 * l4 + j];
+                    const float d = dzs[lz] + dxv.v[j];
                     un.v[j] = (fmaf(2.f, c.v[j], -(1.f - d) * up.v[j]) + q.v[j]) * rcp1(1.f + d);
                 } else {
                     un.v[j] = (2.f * c.v[j] - up.v[j]) + q.v[j];
@@ -230,11 +262,15 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
     };
     static_assert(KS == 2 || KS == 4, "sub-steps are spelled out below");
     substep(std::integral_constant<int, 0>{});
+    FWI_STAMP(2);
     substep(std::integral_constant<int, 1>{});
+    FWI_STAMP(3);
     if constexpr (KS == 4) {
         substep(std::integral_constant<int, 2>{});
+        FWI_STAMP(4);
         substep(std::integral_constant<int, 3>{});
     }
+    FWI_STAMP(5);
 
     // ---- write the interior of the last two time levels (and the gradient contribution) -------------
 #pragma unroll
@@ -256,7 +292,18 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
             *reinterpret_cast<q4 *>(gp) = gv;
         }
     }
+#ifdef FWI_FUSED2D_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // the stores have left the wave
+    FWI_STAMP(6);
+    FWI_STAMP(7);
+#endif
 }
+
+#ifdef FWI_FUSED2D_STAMPS
+extern "C" int fwi_debug_fused2d_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fwi_fused2d_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 int fused2d_num_tiles(const GridDesc &g) {
     return ((g.nx + FUSED2D_TILE - 1) / FUSED2D_TILE) * ((g.nz + FUSED2D_TILE - 1) / FUSED2D_TILE);
@@ -275,7 +322,10 @@ static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
+hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a0, hipStream_t s) {
+    static const bool no_remap = getenv("FWI_FUSED2D_NOREMAP") != nullptr;  // tuning hook
+    Fused2dArgs a = a0;
+    a.xcd_remap = no_remap ? 0 : 1;
     if (g.r == 4) return a.damp ? launch_fused_r<4, true>(g, a, s) : launch_fused_r<4, false>(g, a, s);
     if (g.r == 2) return a.damp ? launch_fused_r<2, true>(g, a, s) : launch_fused_r<2, false>(g, a, s);
     return a.damp ? launch_fused_r<1, true>(g, a, s) : launch_fused_r<1, false>(g, a, s);
