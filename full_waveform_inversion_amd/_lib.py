@@ -15,10 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FWI_HIP_LIB") or os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
+UPDATE_FORMS = {"standard": 0, "increment": 1}
+ABCS = {"sponge": 0, "cpml": 1}
+STORE_DTYPES = {"native": 0, "bf16": 1}
 UNIQUE_ID_BYTES = 128
 ERROR_NAMES = {1: "FWI_EINVAL", 2: "FWI_EHIP", 3: "FWI_ESTATE", 4: "FWI_ENOMEM", 5: "FWI_ECOMM"}
 
@@ -36,8 +39,9 @@ class Config(C.Structure):
                 ("ny", C.c_int32), ("nx", C.c_int32), ("order", C.c_int32), ("nt_max", C.c_int32),
                 ("npml", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
                 ("kernel", C.c_int32), ("zchunk", C.c_int32), ("ckpt_interval", C.c_int32),
-                ("image_stride", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
-                ("sigma_max", C.c_double)]
+                ("image_stride", C.c_int32), ("update_form", C.c_int32), ("abc", C.c_int32),
+                ("store_dtype", C.c_int32), ("reserved0", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
+                ("sigma_max", C.c_double), ("pml_alpha_max", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/fwi.h declares

@@ -51,6 +51,8 @@ struct fwi_ctx {
 
     // device fields
     void *u[2] = {nullptr, nullptr};  // padded wavefields (ping-pong)
+    bool inc = false;                 // increment form: state (u, v = u - u_prev); u[] ping-pongs u, v lives in vf
+    void *vf = nullptr, *fwv = nullptr;  // v of the running sweep / of the checkpointed forward recomputation
     void *C = nullptr;                // padded dt^2 c^2
     void *c_dev = nullptr;            // compact velocity
     void *dz = nullptr, *dy = nullptr, *dx = nullptr;
@@ -220,12 +222,14 @@ struct Impl {
         void *f[2];
         int cur = 0;
         int prev_n = -1;
+        void *v = nullptr;  // increment form: the v field of this sweep
     };
 
     static StepArgs<T> base_args(fwi_ctx *ctx, int cur) {
         StepArgs<T> a;
         a.u_cur = (const T *)ctx->u[cur];
         a.u_prev = (T *)ctx->u[cur ^ 1];
+        a.v = nullptr;
         a.C = (const T *)ctx->C;
         a.dz = (const T *)ctx->dz;
         a.dy = (const T *)ctx->dy;
@@ -582,6 +586,7 @@ struct Impl {
             StepArgs<T> a = base_args(ctx, 0);
             a.u_cur = (const T *)sw.f[sw.cur];
             a.u_prev = (T *)sw.f[sw.cur ^ 1];
+            a.v = (T *)sw.v;
             a.q_out = q_out(n);
             q_in(n, a.q_in, a.q_in2);
             if (inj.n > 0) {
@@ -647,7 +652,7 @@ struct Impl {
             struct { void **p; size_t bytes; bool zero; } want[] = {
                 {&ctx->snap, (size_t)nseg * 2 * fb, false},
                 {&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T), false},  // K slots + carry
-                {&ctx->fwd[0], fb, false}, {&ctx->fwd[1], fb, false},
+                {&ctx->fwd[0], fb, false}, {&ctx->fwd[1], fb, false}, {&ctx->fwv, ctx->inc ? fb : 0, false},
                 {&ctx->fwx[0], ctx->fused2d ? fb : 0, true}, {&ctx->fwx[1], ctx->fused2d ? fb : 0, true}};
             size_t total = 0, fr = 0, tot = 0;
             for (auto &w : want) total += w.bytes;
@@ -691,6 +696,8 @@ struct Impl {
         Sweep sw;
         sw.f[0] = ctx->u[0];
         sw.f[1] = ctx->u[1];
+        sw.v = ctx->vf;
+        if (ctx->inc) HIPCHK(ctx, hipMemsetAsync(ctx->vf, 0, (size_t)g.ptot * sizeof(T), ctx->stream));
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         auto none = [](int) -> T * { return nullptr; };
@@ -705,8 +712,8 @@ struct Impl {
             for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
                 T *sn = (T *)ctx->snap + (size_t)seg * 2 * g.ptot;  // (u^n0, u^{n0-1})
                 HIPCHK(ctx, hipMemcpyAsync(sn, sw.f[sw.cur], (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
-                HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
-                                           hipMemcpyDeviceToDevice, s));
+                HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, ctx->inc ? sw.v : sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
+                                           hipMemcpyDeviceToDevice, s));  // (u^n0, u^{n0-1}) or, increment form, (u^n0, v^n0)
                 const int cnt = std::min(K, nt - n0);
                 if (fused)
                     rc = run_fused(ctx, sw, spare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, &ctx->rec, series,
@@ -762,6 +769,8 @@ struct Impl {
         Sweep sw;
         sw.f[0] = ctx->u[0];
         sw.f[1] = ctx->u[1];
+        sw.v = ctx->vf;
+        if (ctx->inc) HIPCHK(ctx, hipMemsetAsync(ctx->vf, 0, (size_t)g.ptot * sizeof(T), ctx->stream));
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         const T *amp = (const T *)ctx->amp;
@@ -785,7 +794,7 @@ struct Impl {
                     pq[hi - n] = mine;
                     pq2[hi - n] = pending;
                     pending = nullptr;
-                } else if (mine && n > lo && ctx->istride == 1) {
+                } else if (mine && n > lo && ctx->istride == 1 && !ctx->inc) {
                     pending = mine;  // first step of a pair: defer (every step images: the next one pairs)
                 } else {
                     pq[hi - n] = mine;  // single (last step of an odd run, or nothing to pair)
@@ -842,11 +851,12 @@ struct Impl {
                 const int n0 = seg * K, cnt = std::min(K, nt - n0);
                 const T *sn = (const T *)ctx->snap + (size_t)seg * 2 * g.ptot;
                 HIPCHK(ctx, hipMemcpyAsync(ctx->fwd[0], sn, (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->fwd[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
+                HIPCHK(ctx, hipMemcpyAsync(ctx->inc ? ctx->fwv : ctx->fwd[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));
                 Sweep fw;
                 fw.f[0] = ctx->fwd[0];
                 fw.f[1] = ctx->fwd[1];
+                fw.v = ctx->fwv;
                 auto qo = [&](int n) -> T * { return q_store + (size_t)(n - n0) * g.npts; };
                 if ((rc = run_steps(ctx, fw, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr, T(0), qo,
                                     noq)))
@@ -1070,6 +1080,13 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->image_stride < 0) return bad("image_stride must be >= 0");
     if (cfg->image_stride > 1 && cfg->ckpt_interval > 0)
         return bad("image_stride > 1 and ckpt_interval > 0 cannot be combined");
+    if (cfg->update_form != FWI_UPDATE_STANDARD && cfg->update_form != FWI_UPDATE_INCREMENT)
+        return bad("unknown update_form");
+    if (cfg->abc != FWI_ABC_SPONGE && cfg->abc != FWI_ABC_CPML) return bad("unknown abc");
+    if (cfg->store_dtype != FWI_STORE_NATIVE && cfg->store_dtype != FWI_STORE_BF16) return bad("unknown store_dtype");
+    if (cfg->store_dtype == FWI_STORE_BF16 && cfg->dtype != FWI_F32) return bad("store_dtype bf16 needs an fp32 context");
+    if (cfg->reserved0 != 0) return bad("reserved0 must be 0");
+    if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
@@ -1087,12 +1104,21 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->esize = cfg->dtype == FWI_F32 ? 4 : 8;
     ctx->ckpt = cfg->ckpt_interval;
     ctx->istride = cfg->image_stride > 1 ? cfg->image_stride : 1;
+    ctx->inc = cfg->update_form == FWI_UPDATE_INCREMENT;
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
         return bad("STREAM kernel: fp64 is 3-D only");
     }
     ctx->kernel = (cfg->kernel == FWI_KERNEL_POINT || !can_stream) ? K_POINT : K_STREAM;
+    if (ctx->inc && !(cfg->ndim == 3 && cfg->dtype == FWI_F32)) {
+        // the increment form exists in the 3-D fp32 stream kernel and in the point kernel
+        if (cfg->kernel == FWI_KERNEL_STREAM) {
+            delete ctx;
+            return bad("update_form increment: the STREAM kernel takes it for 3-D fp32 only");
+        }
+        ctx->kernel = K_POINT;
+    }
     if (ctx->kernel == K_STREAM) {
         ctx->tune = stream_default_tuning(ctx->gd, cfg->dtype == FWI_F32);
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
@@ -1107,8 +1133,13 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     }
     // 2-D fp32 grids: advance FUSED2D_STEPS time steps per launch (fwi_fused2d.hip) whenever the step
     // count allows it (FWI_NO_FUSED2D is the tuning / comparison hook)
-    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !getenv("FWI_NO_FUSED2D");
+    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc &&
+                   !getenv("FWI_NO_FUSED2D");
     int rc = create_impl(ctx);
+    if (rc == FWI_OK && ctx->inc &&
+        (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
+         hipMemset(ctx->vf, 0, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess))
+        rc = ctx->fail(FWI_ENOMEM, "allocating the increment field failed");
     if (rc == FWI_OK && ctx->fused2d) {
         for (int i = 0; i < 2 && rc == FWI_OK; ++i) {
             if (hipMalloc(&ctx->fx[i], (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
@@ -1132,7 +1163,7 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
                     ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series, ctx->wav, ctx->snap, ctx->fwd[0],
-                    ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1], ctx->logical};
+                    ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1], ctx->logical, ctx->vf, ctx->fwv};
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
                         ps->s_cq, ps->s_col, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace fwi {
 
@@ -48,7 +49,7 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
 // dimension; the fallback for shapes the stream kernel does not take and the
 // on-device cross-check of it.
 // ---------------------------------------------------------------------------
-template <typename T, int R, int NDIM, bool SAVE_Q, bool IMAGE>
+template <typename T, int R, int NDIM, bool SAVE_Q, bool IMAGE, bool INC>
 __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int nbx, int nby, int nblk) {
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if ((int)blockIdx.x >= nblk) {
@@ -81,12 +82,22 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
             lap = fma(a.ck[k], t, lap);
         }
         const T q = a.C[p] * lap;
-        const T up = a.u_prev[p];
+        const T up = INC ? a.v[p] : a.u_prev[p];  // increment form: the operand is v^n = u^n - u^{n-1}
         T un;
         if (a.damp) {
             T d = a.dz[z] + a.dx[x];
             if (NDIM == 3) d += a.dy[y];
-            un = (T(2) * uc - (T(1) - d) * up + q) / (T(1) + d);
+            if (INC) {
+                const T vn = ((T(1) - d) * up + q) / (T(1) + d);
+                a.v[p] = vn;
+                un = uc + vn;
+            } else {
+                un = (T(2) * uc - (T(1) - d) * up + q) / (T(1) + d);
+            }
+        } else if (INC) {
+            const T vn = up + q;
+            a.v[p] = vn;
+            un = uc + vn;
         } else {
             un = (T(2) * uc - up) + q;
         }
@@ -103,6 +114,7 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
             for (int i = s0 + tid; i < s1; i += 256) {
                 const T amp = a.inj_amp[a.inj_col[i]];
                 atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
+                if (INC) atomicAdd(a.v + a.inj_pidx[i], a.inj_cu[i] * amp);  // the source moves u' and v' alike
                 if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
             }
         }
@@ -188,7 +200,7 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 
 // IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
-template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF>
+template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk, int tw) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -302,10 +314,12 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
     V up[NR], Cc[NR], halo[NRH][NH];
     T edge[NR];
+    // increment form: the pointwise operand is v^n (its own padded field) instead of u^{n-1}
+    const T *const pw = INC ? a.v : a.u_prev;
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int64_t o = (int64_t)(z0 + p) * sz;
-        up[p] = ldv<T>(a.u_prev + o + poff);
+        up[p] = ldv<T>(pw + o + poff);
         Cc[p] = ldv<T>(a.C + o + poff);
         edge[p] = a.u_cur[o + eoff];
     }
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             edge[nxt] = a.u_cur[on + eoff];
             // (plain loads: non-temporal hints on these read-once streams were measured and
             // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
-            up[nxt] = ldv<T>(a.u_prev + on + poff);
+            up[nxt] = ldv<T>(pw + on + poff);
             Cc[nxt] = ldv<T>(a.C + on + poff);
             V qi, qi2, gi;
             if (IMAGE) {
@@ -401,16 +415,20 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     }
                 }
             }
-            V q, un;
+            V q, un, vn;
 #pragma unroll
             for (int j = 0; j < VL; ++j) {
                 q.v[j] = Cc[cur].v[j] * lap.v[j];
-                if (DAMP)
+                if (INC) {  // v' = A (B v + q), u' = u + v'
+                    vn.v[j] = DAMP ? fma(B.v[j], up[cur].v[j], q.v[j]) * A.v[j] : up[cur].v[j] + q.v[j];
+                    un.v[j] = X[HALO + j] + vn.v[j];
+                } else if (DAMP)
                     un.v[j] = (fma(T(2), X[HALO + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
                 else
                     un.v[j] = (T(2) * X[HALO + j] - up[cur].v[j]) + q.v[j];
             }
             if (act) {
+                if (INC) stv<T>(a.v + (int64_t)z * sz + poff, vn);
                 stv<T>(a.u_prev + (int64_t)z * sz + poff, un);
                 if (SAVE_Q) stv_stream<T>(a.q_out + (int64_t)z * cplane + coff, q);
                 if (IMAGE) {
@@ -435,6 +453,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
                 const T amp = a.inj_amp[a.inj_col[i]];
                 atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
+                if (INC) atomicAdd(a.v + a.inj_pidx[i], a.inj_cu[i] * amp);  // the source moves u' and v' alike
                 if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
             }
         }
@@ -625,6 +644,20 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
     dim3 block(64, TY), grid(nblk + nrb);
     static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
     if (no_remap) zchunk = -zchunk;
+    if constexpr (std::is_same<T, float>::value) {
+        if (a.v) {  // increment form (fp32 only; the adjoint sweep images one pairing per step)
+            if (a.q_out)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true>), grid, block, 0, s, a, g,
+                                   zchunk, nxt, nyt, nblk, tw);
+            else if (a.q_in)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true>), grid, block, 0, s, a, g,
+                                   zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true>), grid, block, 0, s, a, g,
+                                   zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+    }
     if (a.q_out)
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk, tw);
@@ -733,12 +766,19 @@ static hipError_t launch_point_mode(const GridDesc &g, const StepArgs<T> &a, hip
     point_blocks(g, nbx, nby, nblk);
     const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 1023) / 1024 : 0;
     dim3 block(64, 4), grid(nblk + nrb);
-    if (a.q_out)
-        hipLaunchKernelGGL((step_point<T, R, NDIM, true, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
+    if (a.v) {
+        if (a.q_out)
+            hipLaunchKernelGGL((step_point<T, R, NDIM, true, false, true>), grid, block, 0, s, a, g, nbx, nby, nblk);
+        else if (a.q_in)
+            hipLaunchKernelGGL((step_point<T, R, NDIM, false, true, true>), grid, block, 0, s, a, g, nbx, nby, nblk);
+        else
+            hipLaunchKernelGGL((step_point<T, R, NDIM, false, false, true>), grid, block, 0, s, a, g, nbx, nby, nblk);
+    } else if (a.q_out)
+        hipLaunchKernelGGL((step_point<T, R, NDIM, true, false, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
     else if (a.q_in)
-        hipLaunchKernelGGL((step_point<T, R, NDIM, false, true>), grid, block, 0, s, a, g, nbx, nby, nblk);
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, true, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
     else
-        hipLaunchKernelGGL((step_point<T, R, NDIM, false, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
+        hipLaunchKernelGGL((step_point<T, R, NDIM, false, false, false>), grid, block, 0, s, a, g, nbx, nby, nblk);
     return hipGetLastError();
 }
 

@@ -43,10 +43,14 @@ class Engine:
     ``image_stride = S > 1`` stores and correlates the imaging term every S-th step only (weight S): an
     approximation of the time integral that is accurate while ``S * dt`` still samples the wavelet's
     band, with a store S times smaller and less adjoint traffic.
+    ``update_form="increment"`` carries the recursion as (u, v = u - u_prev): same mathematics, ~4x less fp32
+    round-off growth, 25 % more traffic.  ``abc="cpml"`` replaces the sponge by a convolutional PML.
+    ``store_dtype="bf16"`` halves the forward-term store of an fp32 engine.
     """
 
     def __init__(self, shape, h, dt, nt_max, order=8, npml=0, sigma_max=None, dtype="float32",
-                 device=0, kernel="auto", zchunk=0, ckpt_interval=0, image_stride=1):
+                 device=0, kernel="auto", zchunk=0, ckpt_interval=0, image_stride=1, update_form="standard",
+                 abc="sponge", pml_alpha_max=0.0, store_dtype="native"):
         shape = tuple(int(s) for s in shape)
         if len(shape) not in (2, 3):
             raise ValueError("shape must be (nz, nx) or (nz, ny, nx)")
@@ -63,6 +67,10 @@ class Engine:
         self._zchunk = int(zchunk)
         self._ckpt = int(ckpt_interval)
         self._istride = int(image_stride)
+        self._update_form = _lib.UPDATE_FORMS[update_form]
+        self._abc = _lib.ABCS[abc]
+        self._store_dtype = _lib.STORE_DTYPES[store_dtype]
+        self.pml_alpha_max = float(pml_alpha_max)
         self._lib = _lib.load()
         self._ctx = None
         self._nsrc = self._nrec = self._nt = 0
@@ -78,7 +86,8 @@ class Engine:
         cfg = _lib.Config(C.sizeof(_lib.Config), self.ndim, nz, ny, nx, self.order, self.nt_max,
                           self.npml, self.device,
                           _lib.F32 if self.dtype == np.float32 else _lib.F64, self._kernel,
-                          self._zchunk, self._ckpt, self._istride, self.h, self.dt, float(self.sigma_max))
+                          self._zchunk, self._ckpt, self._istride, self._update_form, self._abc,
+                          self._store_dtype, 0, self.h, self.dt, float(self.sigma_max), self.pml_alpha_max)
         ctx = C.c_void_p()
         _lib.check(None, self._lib.fwi_create(C.byref(cfg), C.byref(ctx)))
         self._ctx = ctx

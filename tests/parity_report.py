@@ -23,7 +23,7 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def case(name, w, nt=None, dtype="float32", kernel="auto"):
+def case(name, w, nt=None, dtype="float32", kernel="auto", **engine_kw):
     if nt:
         w.nt = nt
     wav = w.wavelet(np.float64)
@@ -39,7 +39,7 @@ def case(name, w, nt=None, dtype="float32", kernel="auto"):
     g0 = p0.gradient()
     t_cpu = time.time() - t0
     with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max, dtype=dtype,
-                kernel=kernel) as e:
+                kernel=kernel, **engine_kw) as e:
         dg = e.forward(c0, (src, wav), w.rec_idx, save=True)
         ag = e.adjoint(r)
         gg = e.gradient()
@@ -48,7 +48,7 @@ def case(name, w, nt=None, dtype="float32", kernel="auto"):
         ge = e.gradient()
         kern = e.kernel_name
     out = {"case": name, "shape": list(w.shape), "nt": w.nt, "order": w.order, "npml": w.npml, "dtype": dtype,
-           "kernel": kern, "seis": rel(dg, d0), "adj_src": rel(ag, a0), "grad_same_r": rel(gg, g0),
+           "kernel": kern, "engine_options": engine_kw, "seis": rel(dg, d0), "adj_src": rel(ag, a0), "grad_same_r": rel(gg, g0),
            "grad_e2e": rel(ge, g0), "resid_over_data": float(np.linalg.norm(r) / np.linalg.norm(d0)),
            "oracle_seconds": round(t_cpu, 1)}
     print(json.dumps(out), flush=True)
@@ -69,6 +69,12 @@ def main():
         case("cfg5 128^3 x500 fp64 stream", workloads.cfg5(0.5), dtype="float64"),
         case("cfg5 64^3 x250", workloads.cfg5(0.25)),
         case("cfg5 128^3 x500", workloads.cfg5(0.5)),
+        # the fp32 increment-form update (fwi_config.update_form = 1) beside the standard form above
+        case("cfg2 512^2 x1000 increment (point kernel)", workloads.cfg2(0.5), update_form="increment"),
+        case("cfg2 1024^2 x2000 (full) increment (point kernel)", workloads.cfg2(1.0), update_form="increment"),
+        case("cfg4 128^3 x500 increment", workloads.cfg4(0.5), update_form="increment"),
+        case("cfg5 64^3 x250 increment", workloads.cfg5(0.25), update_form="increment"),
+        case("cfg5 128^3 x500 increment", workloads.cfg5(0.5), update_form="increment"),
     ]
     if len(sys.argv) > 1:
         json.dump(rows, open(sys.argv[1], "w"), indent=1)

@@ -425,6 +425,44 @@ def test_device_residual_and_misfit_equal_the_host_ones(gpu, dtype):
             e.adjoint(None, image=False)
 
 
+@pytest.mark.parametrize("shape,order,npml,dtype,tol,kern", [
+    ((40, 36, 256), 8, 6, "float32", TOL32, "step3d_stream"),   # full 256-column tiles
+    ((33, 29, 50), 8, 5, "float32", TOL32, "step3d_stream"),    # ragged tiles
+    ((30, 28, 36), 4, 0, "float32", TOL32, "step3d_stream"),    # no damping
+    ((30, 28, 36), 8, 4, "float64", TOL64, "step_point"),
+    ((70, 90), 8, 8, "float32", TOL32, "step_point"),           # 2-D: the point kernel carries this form
+    ((70, 90), 2, 0, "float64", TOL64, "step_point")])
+def test_increment_form_matches_the_oracle(gpu, shape, order, npml, dtype, tol, kern):
+    """fwi_config.update_form = INCREMENT: the recursion carried as (u, v = u - u_prev).  Same mathematics as
+    the oracle's standard form, so the same tolerances hold for seismograms, F^T r and the gradient -- with
+    checkpointing (the snapshots hold (u, v)) as without."""
+    rng = np.random.default_rng(5)
+    c = 2000.0 + 600.0 * rng.random(shape)
+    h = 10.0
+    dt = 0.7 * fo.cfl_dt(c.max(), h, len(shape), order)
+    nt = 60
+    src = np.array([[s // 2 for s in shape]])
+    rec = np.array([[max(npml, 2) + 1] + [s // 3 for s in shape[1:]], [s // 2 + 2 for s in shape]])
+    wav = fo.ricker(nt, dt, 0.12 / dt / 8)
+    p = fo.Propagator(c, h, dt, order, npml)
+    d = p.forward(src, wav, rec)
+    r = d * rng.uniform(0.5, 1.5, size=(1, 2))
+    a = p.adjoint(r)
+    g = p.gradient()
+    for K in (0, 16):
+        with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, dtype=dtype,
+                    update_form="increment", ckpt_interval=K) as e:
+            dg = e.forward(c, (src, wav), rec, save=True)
+            assert e.kernel_name == kern
+            ag = e.adjoint(r)
+            gg = e.gradient()
+        assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (K, rel(dg, d), rel(ag, a), rel(gg, g))
+    if len(shape) == 2:
+        with pytest.raises(FwiError):  # the 2-D stream kernels have no increment form: refused, not ignored
+            Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, dtype=dtype,
+                   update_form="increment", kernel="stream")
+
+
 def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
     """cfg5 scaled (3-D, smooth random model): 3 L-BFGS iterations with the GPU dot product."""
     from full_waveform_inversion_amd import shots as sh
