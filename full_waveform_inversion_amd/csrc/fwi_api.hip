@@ -30,6 +30,10 @@ thread_local std::string g_create_error;
 const double COEF2[] = {-2.0, 1.0};
 const double COEF4[] = {-5.0 / 2.0, 4.0 / 3.0, -1.0 / 12.0};
 const double COEF8[] = {-205.0 / 72.0, 8.0 / 5.0, -1.0 / 5.0, 8.0 / 315.0, -1.0 / 560.0};
+// centred first-difference weights d_1 .. d_r (CPML)
+const double DCOEF2[] = {1.0 / 2.0};
+const double DCOEF4[] = {2.0 / 3.0, -1.0 / 12.0};
+const double DCOEF8[] = {4.0 / 5.0, -1.0 / 5.0, 4.0 / 105.0, -1.0 / 280.0};
 
 std::string vformat(const char *fmt, va_list ap) {
     char buf[512];
@@ -53,6 +57,11 @@ struct fwi_ctx {
     void *u[2] = {nullptr, nullptr};  // padded wavefields (ping-pong)
     bool inc = false;                 // increment form: state (u, v = u - u_prev); u[] ping-pongs u, v lives in vf
     void *vf = nullptr, *fwv = nullptr;  // v of the running sweep / of the checkpointed forward recomputation
+    // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
+    bool cpml = false;
+    void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
+    void *pml_a[3] = {nullptr, nullptr, nullptr}, *pml_b[3] = {nullptr, nullptr, nullptr};
+    size_t pml_bytes[3] = {0, 0, 0};
     void *C = nullptr;                // padded dt^2 c^2
     void *c_dev = nullptr;            // compact velocity
     void *dz = nullptr, *dy = nullptr, *dx = nullptr;
@@ -241,7 +250,7 @@ struct Impl {
         const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
         for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / (ctx->cfg.h * ctx->cfg.h));
-        a.damp = ctx->cfg.npml > 0;
+        a.damp = ctx->cfg.npml > 0 && !ctx->cpml;
         a.npml = ctx->cfg.npml;
         a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
                                   ((double)ctx->cfg.npml * ctx->cfg.npml)) : T(0);
@@ -254,6 +263,38 @@ struct Impl {
         a.rec_scale = T(0);
         a.nrec = 0;
         return a;
+    }
+
+    static PmlArgs<T> pml_args(fwi_ctx *ctx, const Sweep &sw, T *q_out) {
+        PmlArgs<T> p;
+        p.u_cur = (const T *)sw.f[sw.cur];
+        p.u_next = (T *)sw.f[sw.cur ^ 1];
+        p.v = (T *)sw.v;
+        p.C = (const T *)ctx->C;
+        p.q_out = q_out;
+        for (int d = 0; d < 3; ++d) {
+            p.psi[d] = (T *)ctx->pml_psi[d];
+            p.zeta[d] = (T *)ctx->pml_zeta[d];
+            p.a[d] = (const T *)ctx->pml_a[d];
+            p.b[d] = (const T *)ctx->pml_b[d];
+        }
+        const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
+        const double *dc = ctx->cfg.order == 2 ? DCOEF2 : ctx->cfg.order == 4 ? DCOEF4 : DCOEF8;
+        const double h = ctx->cfg.h;
+        for (int k = 0; k < 5; ++k) p.ck[k] = p.dk[k] = T(0);
+        for (int k = 0; k <= ctx->gd.r; ++k) p.ck[k] = (T)(co[k] / (h * h));
+        for (int k = 1; k <= ctx->gd.r; ++k) p.dk[k] = (T)(dc[k - 1] / h);
+        p.npml = ctx->cfg.npml;
+        return p;
+    }
+
+    static int pml_zero(fwi_ctx *ctx) {
+        for (int d = 0; d < 3; ++d)
+            if (ctx->pml_psi[d]) {
+                HIPCHK(ctx, hipMemsetAsync(ctx->pml_psi[d], 0, ctx->pml_bytes[d], ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->pml_zeta[d], 0, ctx->pml_bytes[d], ctx->stream));
+            }
+        return FWI_OK;
     }
 
     // Host arrays are model-shaped (row stride nx); compact device arrays have row stride cx (nx
@@ -604,7 +645,15 @@ struct Impl {
                 a.rec_scale = out_scale;
                 a.nrec = out->n;
             }
-            HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
+            if (ctx->cpml) {  // memory variables of the border advance with the newest field ...
+                const PmlArgs<T> p = pml_args(ctx, sw, a.q_out);
+                HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream));
+                HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream));
+                HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
+                HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream));  // ... and their term joins u' (and q)
+            } else {
+                HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
+            }
             sw.prev_n = n;
             sw.cur ^= 1;
         }
@@ -698,6 +747,7 @@ struct Impl {
         sw.f[1] = ctx->u[1];
         sw.v = ctx->vf;
         if (ctx->inc) HIPCHK(ctx, hipMemsetAsync(ctx->vf, 0, (size_t)g.ptot * sizeof(T), ctx->stream));
+        if (ctx->cpml && (rc = pml_zero(ctx))) return rc;
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         auto none = [](int) -> T * { return nullptr; };
@@ -771,6 +821,7 @@ struct Impl {
         sw.f[1] = ctx->u[1];
         sw.v = ctx->vf;
         if (ctx->inc) HIPCHK(ctx, hipMemsetAsync(ctx->vf, 0, (size_t)g.ptot * sizeof(T), ctx->stream));
+        if (ctx->cpml && (rc = pml_zero(ctx))) return rc;
         T *q_store = (T *)ctx->q_store;
         T *series = (T *)ctx->series;
         const T *amp = (const T *)ctx->amp;
@@ -1018,9 +1069,40 @@ int create_impl(fwi_ctx *ctx) {
     HIPCHK(ctx, hipMalloc(&ctx->dx, (size_t)g.nx * es));
     HIPCHK(ctx, hipMalloc((void **)&ctx->red, 64));
     double sm = c.sigma_max;
-    profile(ctx->pz, g.nz, c.npml, sm, c.dt);
-    profile(ctx->px, g.nx, c.npml, sm, c.dt);
-    if (g.ndim == 3) profile(ctx->py, g.ny, c.npml, sm, c.dt); else ctx->py.assign(1, 0.0);
+    const int np_sponge = ctx->cpml ? 0 : c.npml;  // with the CPML the damping factors are off (A = B = 1)
+    profile(ctx->pz, g.nz, np_sponge, sm, c.dt);
+    profile(ctx->px, g.nx, np_sponge, sm, c.dt);
+    if (g.ndim == 3) profile(ctx->py, g.ny, np_sponge, sm, c.dt); else ctx->py.assign(1, 0.0);
+    if (ctx->cpml) {
+        const int nd[3] = {g.nz, g.ny, g.nx};
+        for (int d = 0; d < 3; ++d) {
+            if (d == 1 && g.ndim == 2) continue;
+            const int n = nd[d], nslab = std::min(n, 2 * c.npml);
+            size_t cnt = (size_t)nslab;
+            for (int o = 0; o < 3; ++o)
+                if (o != d) cnt *= (size_t)nd[o];
+            ctx->pml_bytes[d] = cnt * es;
+            HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d]));
+            HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d]));
+            HIPCHK(ctx, hipMalloc(&ctx->pml_a[d], (size_t)n * es));
+            HIPCHK(ctx, hipMalloc(&ctx->pml_b[d], (size_t)n * es));
+            std::vector<double> pa(n), pb(n);  // cpml_profiles() of the oracle
+            for (int i = 0; i < n; ++i) {
+                const double dist = std::max(0.0, std::max((double)c.npml - i, (double)i - (n - 1 - c.npml)));
+                const double x = dist / c.npml, sig = sm * x * x, alp = c.pml_alpha_max * (1.0 - x);
+                pb[i] = std::exp(-(sig + alp) * c.dt);
+                pa[i] = sig > 0.0 ? sig / (sig + alp) * (pb[i] - 1.0) : 0.0;
+            }
+            int rc2;
+            if (c.dtype == FWI_F32) {
+                if ((rc2 = upload_vec<float>(ctx, ctx->pml_a[d], pa)) || (rc2 = upload_vec<float>(ctx, ctx->pml_b[d], pb)))
+                    return rc2;
+            } else {
+                if ((rc2 = upload_vec<double>(ctx, ctx->pml_a[d], pa)) || (rc2 = upload_vec<double>(ctx, ctx->pml_b[d], pb)))
+                    return rc2;
+            }
+        }
+    }
     int rc;
     if (c.dtype == FWI_F32) {
         if ((rc = upload_vec<float>(ctx, ctx->dz, ctx->pz))) return rc;
@@ -1087,6 +1169,8 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->store_dtype == FWI_STORE_BF16 && cfg->dtype != FWI_F32) return bad("store_dtype bf16 needs an fp32 context");
     if (cfg->reserved0 != 0) return bad("reserved0 must be 0");
     if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
+    if (cfg->abc == FWI_ABC_CPML && cfg->npml > 0 && cfg->ckpt_interval > 0)
+        return bad("abc cpml and ckpt_interval > 0 cannot be combined (the snapshots do not hold the memory variables)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
@@ -1105,6 +1189,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->ckpt = cfg->ckpt_interval;
     ctx->istride = cfg->image_stride > 1 ? cfg->image_stride : 1;
     ctx->inc = cfg->update_form == FWI_UPDATE_INCREMENT;
+    ctx->cpml = cfg->abc == FWI_ABC_CPML && cfg->npml > 0;
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;
@@ -1133,7 +1218,8 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     }
     // 2-D fp32 grids: advance FUSED2D_STEPS time steps per launch (fwi_fused2d.hip) whenever the step
     // count allows it (FWI_NO_FUSED2D is the tuning / comparison hook)
-    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc &&
+    // (the CPML's slab kernels run between time steps: one step per launch, the tile kernel)
+    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml &&
                    !getenv("FWI_NO_FUSED2D");
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
@@ -1173,6 +1259,9 @@ void fwi_destroy(fwi_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (void *v : ctx->vecs)
         if (v) (void)hipFree(v);
+    for (int d = 0; d < 3; ++d)
+        for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d]})
+            if (q) (void)hipFree(q);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -118,6 +118,24 @@ hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_
 template <typename T>
 hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out, hipStream_t s);
 
+// ---- convolutional PML (fwi_pml.hip): slab kernels around the undamped step kernels ------------------------
+template <typename T>
+struct PmlArgs {
+    const T *u_cur;   // the newest field (padded): u^n forward, mu^{j+2} in the adjoint sweep
+    T *u_next;        // the field the step kernel has just written (phase 3 adds the border term to it)
+    T *v;             // increment form: v' of the step, or nullptr
+    const T *C;       // dt^2 c^2, padded
+    T *q_out;         // compact forward term of this step (phase 3 adds the border term), or nullptr
+    T *psi[3], *zeta[3];    // memory variables per axis (z, y, x), compact over that axis' border; [1] unused in 2-D
+    const T *a[3], *b[3];   // 1-D coefficients per axis
+    T ck[5];          // second-difference weights / h^2 (ck[0] = centre)
+    T dk[5];          // first-difference weights / h, k = 1..r
+    int npml;
+};
+// phase 1, 2: advance the memory variables (before the step kernel); 3: add their term to u' (after it)
+template <typename T>
+hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s);
+
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch
 constexpr int FUSED2D_TILE = 64;   // interior tile edge (points); extended edge = TILE + 2 STEPS r

@@ -1,0 +1,183 @@
+// Convolutional PML (fwi_config.abc = FWI_ABC_CPML): the memory variables of the absorbing border and their
+// contribution to the time step, as slab kernels around the unchanged (undamped) step kernels.
+//
+// No reference counterpart; the recursion and its exact transpose are stated at the top of
+// oracle/fwi_oracle.py.  Per axis d the memory variables psi_d, zeta_d exist in that axis' border only
+// (`nslab` = 2 npml planes of the grid, stored compactly), with 1-D coefficients a_d, b_d:
+//
+//   forward                                   adjoint sweep (mu = the newest adjoint field)
+//   K1  psi  <- b psi  + a D u                zt <- b zt + mu
+//   K2  zeta <- b zeta + a (E u + D psi)      pt <- b pt - D mu - D (a zt)
+//   --- the step kernel: u' = 2u - u_prev + C (L u + injection) ---
+//   K3  u' += C (D psi + zeta)  [q too]       u' += C (E (a zt) - D (a pt))
+//
+// D = centred first difference, E = second-difference star along d.  K3 covers the border widened by the stencil
+// radius (D psi reaches that far).  These are bandwidth-trivial kernels over <= 2 (npml + r) planes per axis.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "fwi_kernels.h"
+
+namespace fwi {
+
+namespace {
+
+// grid index of slab plane j, and slab plane of grid index i (-1: not in the border)
+__device__ __forceinline__ int slab_to_grid(int j, int n, int npml) {
+    return (n <= 2 * npml || j < npml) ? j : n - 2 * npml + j;
+}
+__device__ __forceinline__ int grid_to_slab(int i, int n, int npml) {
+    if (i < 0 || i >= n) return -1;
+    if (n <= 2 * npml || i < npml) return i;
+    return i >= n - npml ? i - (n - 2 * npml) : -1;
+}
+
+template <typename T>
+struct AxisView {
+    int d;            // 0 = z, 1 = y, 2 = x
+    int n, npml;      // grid extent along d, border width
+    int64_t gst;      // stride of the padded fields along d
+    int64_t ast;      // stride of the compact memory-variable arrays along d
+    const T *a, *b;   // 1-D coefficients (length n)
+};
+
+// value of a memory variable at grid index i along d (0 outside the border), given the aux offset of the other
+// two coordinates
+template <typename T>
+__device__ __forceinline__ T aux_at(const T *aux, const AxisView<T> &v, int64_t base, int i) {
+    const int j = grid_to_slab(i, v.n, v.npml);
+    return j < 0 ? T(0) : aux[base + (int64_t)j * v.ast];
+}
+
+}  // namespace
+
+// One thread per point of the region: the border of axis d (phase 1, 2) or the border widened by R (phase 3).
+// dims of the region: (e0, e1, e2) = (z, y, x) extents with the d extent replaced by the region's plane count.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g, int phase, int d, int reverse) {
+    const int nd[3] = {g.nz, g.ny, g.nx};
+    const int n = nd[d], npml = p.npml;
+    const int nslab = min(n, 2 * npml);
+    const int wide = min(n, 2 * (npml + R));  // planes of the widened region
+    const int ext = phase == 3 ? wide : nslab;
+    int e[3] = {g.nz, g.ny, g.nx};
+    e[d] = ext;
+    const int64_t total = (int64_t)e[0] * e[1] * e[2];
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int c[3];
+    c[2] = (int)(t % e[2]);
+    c[1] = (int)((t / e[2]) % e[1]);
+    c[0] = (int)(t / ((int64_t)e[2] * e[1]));
+    // grid coordinate along d
+    const int jd = c[d];
+    int i;
+    if (phase == 3)
+        i = (n <= 2 * (npml + R) || jd < npml + R) ? jd : n - 2 * (npml + R) + jd;
+    else
+        i = slab_to_grid(jd, n, npml);
+    int gc[3] = {c[0], c[1], c[2]};
+    gc[d] = i;
+    const int64_t gstr[3] = {g.sz, g.sy, 1};
+    const int64_t pp = g.off0 + (int64_t)gc[0] * g.sz + (int64_t)gc[1] * g.sy + gc[2];  // padded index
+    // compact aux arrays of axis d: extents (nz, ny, nx) with the d extent = nslab, x fastest
+    int ae[3] = {g.nz, g.ny, g.nx};
+    ae[d] = nslab;
+    const int64_t astr[3] = {(int64_t)ae[1] * ae[2], ae[2], 1};
+    int ac[3] = {gc[0], gc[1], gc[2]};
+    ac[d] = 0;
+    const int64_t abase = (int64_t)ac[0] * astr[0] + (int64_t)ac[1] * astr[1] + ac[2];  // aux offset at slab plane 0
+    AxisView<T> v{d, n, npml, gstr[d], astr[d], p.a[d], p.b[d]};
+    T *psi = p.psi[d], *zet = p.zeta[d];
+    const T *u = p.u_cur + pp;
+    const int64_t gs = v.gst;
+
+    if (phase == 1) {
+        const int64_t ai = abase + (int64_t)jd * v.ast;
+        if (!reverse) {
+            T du = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) du = fma(p.dk[k], u[k * gs] - u[-k * gs], du);
+            psi[ai] = fma(v.b[i], psi[ai], v.a[i] * du);
+        } else {
+            zet[ai] = fma(v.b[i], zet[ai], u[0]);
+        }
+    } else if (phase == 2) {
+        const int64_t ai = abase + (int64_t)jd * v.ast;
+        if (!reverse) {
+            T e2 = p.ck[0] * u[0], dp = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                e2 = fma(p.ck[k], u[k * gs] + u[-k * gs], e2);
+                dp = fma(p.dk[k], aux_at(psi, v, abase, i + k) - aux_at(psi, v, abase, i - k), dp);
+            }
+            zet[ai] = fma(v.b[i], zet[ai], v.a[i] * (e2 + dp));
+        } else {
+            T du = T(0), da = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                du = fma(p.dk[k], u[k * gs] - u[-k * gs], du);
+                const int ip = i + k, im = i - k;
+                const T ap = (ip < n) ? v.a[ip] * aux_at(zet, v, abase, ip) : T(0);
+                const T am = (im >= 0) ? v.a[im] * aux_at(zet, v, abase, im) : T(0);
+                da = fma(p.dk[k], ap - am, da);
+            }
+            psi[ai] = v.b[i] * psi[ai] - du - da;
+        }
+    } else {
+        T term;
+        if (!reverse) {
+            T dp = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+                dp = fma(p.dk[k], aux_at(psi, v, abase, i + k) - aux_at(psi, v, abase, i - k), dp);
+            term = dp + aux_at(zet, v, abase, i);
+        } else {
+            const int j0 = grid_to_slab(i, n, npml);
+            T e2 = (j0 >= 0) ? p.ck[0] * v.a[i] * zet[abase + (int64_t)j0 * v.ast] : T(0), db = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const int ip = i + k, im = i - k;
+                const T ap = (ip < n) ? v.a[ip] : T(0), am = (im >= 0) ? v.a[im] : T(0);
+                e2 = fma(p.ck[k], ap * aux_at(zet, v, abase, ip) + am * aux_at(zet, v, abase, im), e2);
+                db = fma(p.dk[k], ap * aux_at(psi, v, abase, ip) - am * aux_at(psi, v, abase, im), db);
+            }
+            term = e2 - db;
+        }
+        const T add = p.C[pp] * term;
+        p.u_next[pp] += add;
+        if (p.v) p.v[pp] += add;  // increment form: the step's v' = u' - u moves with u'
+        if (p.q_out) p.q_out[((int64_t)gc[0] * g.ny + gc[1]) * g.cx + gc[2]] += add;
+    }
+}
+
+template <typename T, int R>
+static hipError_t launch_pml_r(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
+    const int nd[3] = {g.nz, g.ny, g.nx};
+    for (int d = 0; d < 3; ++d) {
+        if (d == 1 && g.ndim == 2) continue;
+        const int ext = phase == 3 ? std::min(nd[d], 2 * (p.npml + R)) : std::min(nd[d], 2 * p.npml);
+        int64_t total = ext;
+        for (int o = 0; o < 3; ++o)
+            if (o != d) total *= nd[o];
+        if (total <= 0) continue;
+        hipLaunchKernelGGL((pml_kernel<T, R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, g, phase, d,
+                           reverse);
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
+    switch (g.r) {
+        case 1: return launch_pml_r<T, 1>(g, p, phase, reverse, s);
+        case 2: return launch_pml_r<T, 2>(g, p, phase, reverse, s);
+        default: return launch_pml_r<T, 4>(g, p, phase, reverse, s);
+    }
+}
+
+template hipError_t launch_pml<float>(const GridDesc &, const PmlArgs<float> &, int, int, hipStream_t);
+template hipError_t launch_pml<double>(const GridDesc &, const PmlArgs<double> &, int, int, hipStream_t);
+
+}  // namespace fwi

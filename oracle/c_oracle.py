@@ -44,14 +44,14 @@ def lib():
     if _lib is None:
         os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))
         _lib = ctypes.CDLL(build())
-        f = _lib.fwi_oracle_propagate
+        f = _lib.fwi_oracle_propagate_abc
         f.restype = ctypes.c_int
         dp = ctypes.POINTER(ctypes.c_double)
         ip = ctypes.POINTER(ctypes.c_int64)
         f.argtypes = [ctypes.c_int] * 5 + [dp, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ip, dp, ctypes.c_double, ctypes.c_int, ip, ctypes.c_double,
-                                           dp, ctypes.c_int, dp, dp]
+                                           dp, ctypes.c_int, dp, dp, ctypes.c_int, ctypes.c_double]
     return _lib
 
 
@@ -66,7 +66,10 @@ def _ip(a):
 class CPropagator:
     """fp64 forward/adjoint/gradient through the C oracle."""
 
-    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, threads=None, image_stride=1):
+    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, threads=None, image_stride=1, abc="sponge",
+                 pml_alpha_max=0.0):
+        self.abc = {"sponge": 0, "cpml": 1}[abc]
+        self.pml_alpha_max = float(pml_alpha_max)
         self.image_stride = max(1, int(image_stride))  # see Propagator: imaging every S-th step, weight S
         self.c = np.ascontiguousarray(c, np.float64)
         self.shape = self.c.shape
@@ -82,10 +85,10 @@ class CPropagator:
         ny = self.shape[1] if self.ndim == 3 else 1
         nt = amp.shape[0]
         out = np.zeros((nt, len(rec)))
-        rc = lib().fwi_oracle_propagate(
+        rc = lib().fwi_oracle_propagate_abc(
             self.ndim, nz, ny, nx, self.order, _dp(self.c), self.h, self.dt, self.npml,
             self.sigma_max, nt, int(reverse), len(inj), _ip(inj), _dp(amp), inj_scale, len(rec),
-            _ip(rec), rec_scale, _dp(out), int(save_q), _dp(self.q_store), _dp(image))
+            _ip(rec), rec_scale, _dp(out), int(save_q), _dp(self.q_store), _dp(image), self.abc, self.pml_alpha_max)
         if rc:
             raise RuntimeError("fwi_oracle_propagate failed with code %d" % rc)
         return out

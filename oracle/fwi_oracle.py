@@ -33,6 +33,25 @@ Adjoint (exact transpose of the above), j = nt-1 .. 0:
     mu^{j+1} = A * (2 mu^{j+2} - B mu^{j+3} + C * (L mu^{j+2} + R^T r^j))
     a^j      = P^T mu^{j+1} / h^D                  (= (F^T r)^j)
 
+Second absorbing boundary, ``abc="cpml"`` (convolutional PML, memory variables psi_d, zeta_d per axis d, non-zero
+in that axis' ``npml`` border only; the sponge is off: A = B = 1).  With D_d the centred first difference of the
+same order and E_d the second-difference star along d (L = sum_d E_d), per-axis 1-D coefficients
+``b = exp(-(sigma + alpha) dt)``, ``a = sigma / (sigma + alpha) (b - 1)``, ``sigma = sigma_max (dist/npml)^2``,
+``alpha = alpha_max (1 - dist/npml)``:
+
+    psi_d  <- b psi_d  + a D_d u^n
+    zeta_d <- b zeta_d + a (E_d u^n + D_d psi_d)
+    q^n     = C * (L u^n + sum_d (D_d psi_d + zeta_d) + P w^n / h^D),   u^{n+1} = 2 u^n - u^{n-1} + q^n
+
+Its exact transpose, in the scaled adjoint variable mu = C * (adjoint of u) that makes the main recursion the
+forward one again (D_d is antisymmetric, E_d symmetric on the zero-extended grid), j = nt-1 .. 0:
+
+    zt_d <- b zt_d + mu^{j+2},                         alpha_d = a zt_d
+    pt_d <- b pt_d - D_d mu^{j+2} - D_d alpha_d,       beta_d  = a pt_d
+    mu^{j+1} = 2 mu^{j+2} - mu^{j+3} + C * (L mu^{j+2} + sum_d (E_d alpha_d - D_d beta_d) + R^T r^j)
+
+The gradient formula below is unchanged (the model enters through C only; q^n includes the PML terms).
+
 Gradient of ``J = 1/2 sum (d - d_obs)^2`` w.r.t. squared slowness m = 1/c^2
 (zero-lag correlation of the adjoint field with the stored forward term q):
 
@@ -85,6 +104,30 @@ def damping_profiles(shape, npml, sigma_max, dt):
     return out
 
 
+# Centred first-difference weights d_1 .. d_r for order 2r (D u = sum_k d_k (u[+k] - u[-k]) / h).
+DCOEFFS = {
+    2: (1.0 / 2.0,),
+    4: (2.0 / 3.0, -1.0 / 12.0),
+    8: (4.0 / 5.0, -1.0 / 5.0, 4.0 / 105.0, -1.0 / 280.0),
+}
+
+
+def cpml_profiles(shape, npml, sigma_max, alpha_max, dt):
+    """Per-axis 1-D CPML coefficients (a, b); a = 0 outside the npml border."""
+    out = []
+    for n in shape:
+        i = np.arange(n, dtype=np.float64)
+        dist = np.maximum(0.0, np.maximum(npml - i, i - (n - 1 - npml))) if npml > 0 else np.zeros(n)
+        x = dist / max(npml, 1)
+        sig = sigma_max * x ** 2
+        alp = alpha_max * (1.0 - x)
+        b = np.exp(-(sig + alp) * dt)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            a = np.where(sig > 0.0, sig / (sig + alp) * (b - 1.0), 0.0)
+        out.append((a, b))
+    return out
+
+
 def _ravel_idx(idx, shape):
     idx = np.asarray(idx, dtype=np.int64).reshape(-1, len(shape))
     for a, n in enumerate(shape):
@@ -96,7 +139,8 @@ def _ravel_idx(idx, shape):
 class Propagator:
     """fp64 (or any ``dtype``) restatement of one shot's forward/adjoint/gradient."""
 
-    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, dtype=np.float64, image_stride=1):
+    def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, dtype=np.float64, image_stride=1,
+                 abc="sponge", pml_alpha_max=0.0):
         c = np.asarray(c, dtype=np.float64)
         # image_stride S > 1: the imaging condition is a Riemann sum over every S-th step,
         # img = S * sum_{n % S == 0} mu^{n+1} q^n  (the engine's fwi_config.image_stride)
@@ -117,7 +161,20 @@ class Propagator:
         if sigma_max is None:
             sigma_max = default_sigma_max(c.max(), h, npml)
         self.sigma_max = float(sigma_max)
-        prof = damping_profiles(self.shape, self.npml, self.sigma_max, self.dt)
+        if abc not in ("sponge", "cpml"):
+            raise ValueError("abc must be 'sponge' or 'cpml'")
+        self.abc = abc
+        self.pml_alpha_max = float(pml_alpha_max)
+        prof = damping_profiles(self.shape, self.npml if abc == "sponge" else 0, self.sigma_max, self.dt)
+        self.cpml = None
+        if abc == "cpml" and self.npml > 0:
+            self.cpml = []
+            for ax, (a, b) in enumerate(cpml_profiles(self.shape, self.npml, self.sigma_max, self.pml_alpha_max,
+                                                      self.dt)):
+                sh = [1] * self.ndim
+                sh[ax] = -1
+                self.cpml.append((a.reshape(sh).astype(self.dtype), b.reshape(sh).astype(self.dtype)))
+            self.dcoef = [self.dtype.type(dk / self.h) for dk in DCOEFFS[order]]
         d = np.zeros(self.shape)
         for a, p in enumerate(prof):
             sh = [1] * self.ndim
@@ -149,6 +206,56 @@ class Propagator:
             lap = lap + self.coef[k] * acc
         return lap
 
+    def _d1(self, u, ax):
+        """Centred first difference along axis ``ax`` (zero outside the grid): antisymmetric."""
+        r = self.r
+        pad = [(0, 0)] * self.ndim
+        pad[ax] = (r, r)
+        p = np.pad(u, pad)
+        n = self.shape[ax]
+        out = np.zeros(self.shape, self.dtype)
+        for k in range(1, r + 1):
+            hi = [slice(None)] * self.ndim
+            lo = [slice(None)] * self.ndim
+            hi[ax] = slice(r + k, r + k + n)
+            lo[ax] = slice(r - k, r - k + n)
+            out = out + self.dcoef[k - 1] * (p[tuple(hi)] - p[tuple(lo)])
+        return out
+
+    def _d2(self, u, ax):
+        """Second-difference star along axis ``ax`` (the Laplacian is the sum of these over the axes)."""
+        r = self.r
+        pad = [(0, 0)] * self.ndim
+        pad[ax] = (r, r)
+        p = np.pad(u, pad)
+        n = self.shape[ax]
+        out = self.coef[0] * u
+        for k in range(1, r + 1):
+            hi = [slice(None)] * self.ndim
+            lo = [slice(None)] * self.ndim
+            hi[ax] = slice(r + k, r + k + n)
+            lo[ax] = slice(r - k, r - k + n)
+            out = out + self.coef[k] * (p[tuple(hi)] + p[tuple(lo)])
+        return out
+
+    def _cpml_term(self, u, aux, reverse):
+        """Advance the memory variables one step with the newest field ``u`` and return their contribution to
+        the bracket of q (forward recursion, or its transpose for the adjoint sweep)."""
+        term = np.zeros(self.shape, self.dtype)
+        for ax, (a, b) in enumerate(self.cpml):
+            p_, z_ = aux[ax]
+            if not reverse:
+                p_ = b * p_ + a * self._d1(u, ax)
+                z_ = b * z_ + a * (self._d2(u, ax) + self._d1(p_, ax))
+                term = term + self._d1(p_, ax) + z_
+            else:
+                z_ = b * z_ + u
+                al = a * z_
+                p_ = b * p_ - self._d1(u, ax) - self._d1(al, ax)
+                term = term + self._d2(al, ax) - self._d1(a * p_, ax)
+            aux[ax] = (p_, z_)
+        return term
+
     def _propagate(self, inj_flat, inj_amp, inj_scale, rec_flat, rec_scale, nt,
                    reverse, save_q=False, image_q=None):
         """Shared time loop: inject ``inj_amp[n]`` at ``inj_flat``, record at ``rec_flat``."""
@@ -159,10 +266,13 @@ class Propagator:
         qs = np.zeros((nt,) + self.shape, dt_) if save_q else None
         img = np.zeros(self.shape, np.float64) if image_q is not None else None
         steps = range(nt - 1, -1, -1) if reverse else range(nt)
+        aux = [(np.zeros(self.shape, dt_), np.zeros(self.shape, dt_)) for _ in range(self.ndim)] if self.cpml else None
         for n in steps:
             src = np.zeros(self.shape, dt_)
             if len(inj_flat):
                 np.add.at(src.reshape(-1), inj_flat, inj_amp[n] * dt_.type(inj_scale))
+            if self.cpml:
+                src = src + self._cpml_term(u_cur, aux, reverse)
             q = self.C * (self.laplacian(u_cur) + src)
             u_next = self.A * (2 * u_cur - self.B * u_prev + q)
             if save_q:

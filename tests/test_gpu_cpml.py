@@ -1,0 +1,101 @@
+"""The convolutional PML (fwi_config.abc = FWI_ABC_CPML) on the GPU against the CPU oracle: seismograms, F^T r and
+gradient; the exact adjoint identity in fp64; absorption against the sponge at equal border width."""
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import Engine, FwiError, workloads
+from oracle import fwi_oracle as fo
+from oracle.c_oracle import CPropagator
+
+pytestmark = pytest.mark.gpu
+TOL32, TOL64 = 1e-5, 1e-10
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(b))
+
+
+CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
+    ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {}),
+    ((33, 29, 50), 4, 5, 0.0, "float32", TOL32, "step3d_stream", {}),
+    ((40, 36, 44), 8, 6, 30.0, "float64", TOL64, "step3d_stream", {}),
+    ((22, 9, 30), 2, 5, 20.0, "float64", TOL64, "step3d_stream", {}),     # ny < 2 npml: the y borders overlap
+    ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {"update_form": "increment"}),
+    ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step_point", {"kernel": "point"}),
+    ((70, 90), 8, 8, 40.0, "float32", TOL32, "step2d_tile", {}),          # 2-D: one step per launch with the CPML
+    ((70, 91), 2, 7, 0.0, "float32", TOL32, "step2d_tile", {}),
+    ((70, 90), 8, 8, 40.0, "float64", TOL64, "step_point", {}),
+]
+
+
+@pytest.mark.parametrize("shape,order,npml,alpha,dtype,tol,kern,kw", CASES)
+def test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw):
+    rng = np.random.default_rng(11)
+    c = 2000.0 + 600.0 * rng.random(shape)
+    h = 10.0
+    dt = 0.7 * fo.cfl_dt(c.max(), h, len(shape), order)
+    nt = 70
+    src = np.array([[s // 2 for s in shape], [2] + [s // 3 for s in shape[1:]]])  # one source inside the border
+    rec = np.array([[1] + [s // 3 for s in shape[1:]], [s // 2 + 2 for s in shape], [s - 2 for s in shape]])
+    wav = np.stack([fo.ricker(nt, dt, 0.12 / dt / 8), 0.5 * fo.ricker(nt, dt, 0.12 / dt / 6)], 1)
+    p = fo.Propagator(c, h, dt, order, npml, abc="cpml", pml_alpha_max=alpha)
+    d = p.forward(src, wav, rec)
+    r = d * rng.uniform(0.5, 1.5, size=(1, len(rec))) + 0.1 * np.roll(d, 2, axis=0)
+    a = p.adjoint(r)
+    g = p.gradient()
+    with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, dtype=dtype, abc="cpml",
+                pml_alpha_max=alpha, **kw) as e:
+        dg = e.forward(c, (src, wav), rec, save=True)
+        assert e.kernel_name == kern
+        ag = e.adjoint(r)
+        gg = e.gradient()
+        dg2 = e.forward(None, (src, wav), rec, save=False)  # the memory variables restart from zero
+    assert np.array_equal(dg, dg2) or rel(dg2, dg) < 1e-6
+    assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (rel(dg, d), rel(ag, a), rel(gg, g))
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 44), (60, 52)])
+def test_cpml_adjoint_identity_fp64_on_gpu(gpu, shape):
+    rng = np.random.default_rng(4)
+    c = 1800.0 + 900.0 * rng.random(shape)
+    h, order, npml, nt = 10.0, 8, 6, 90
+    dt = 0.7 * fo.cfl_dt(c.max(), h, len(shape), order)
+    src = np.stack([rng.integers(0, s, 3) for s in shape], 1)
+    rec = np.stack([rng.integers(0, s, 5) for s in shape], 1)
+    w, r = rng.standard_normal((nt, 3)), rng.standard_normal((nt, 5))
+    with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=700.0, dtype="float64", abc="cpml",
+                pml_alpha_max=35.0) as e:
+        d = e.forward(c, (src, w), rec, save=False)
+        a = e.adjoint(r, image=False)
+    lhs, rhs = float(np.sum(d * r)), float(np.sum(w * a))
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+
+
+def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
+    """cfg2-like homogeneous 2-D run, 10-cell border, fp32: residual reflection against a large-grid reference."""
+    h, order, c0, n, big, npml, f0 = 10.0, 8, 2000.0, 128, 420, 10, 12.0
+    dt = 0.7 * fo.cfl_dt(c0, h, 2, order)
+    nt = 600
+    w = fo.ricker(nt, dt, f0).astype(np.float32)
+
+    def run(nn, abc, width):
+        off = (nn - n) // 2
+        rec = np.array([[off + npml + 2, off + x] for x in range(npml + 2, n - npml - 2, 4)])
+        with Engine((nn, nn), h, dt, nt, order=order, npml=width, abc=abc) as e:
+            return e.forward(np.full((nn, nn), c0, np.float32), (np.array([[off + n // 2, off + n // 2]]), w), rec,
+                             save=False)
+
+    ref = run(big, "sponge", 0)
+    e_sponge, e_cpml = rel(run(n, "sponge", npml), ref), rel(run(n, "cpml", npml), ref)
+    assert e_sponge > 0.05 and e_cpml < 2e-3
+
+
+def test_cpml_configuration_errors(gpu):
+    with pytest.raises(FwiError) as ei:
+        Engine((32, 32), 10.0, 1e-3, 8, npml=4, sigma_max=100.0, abc="cpml", ckpt_interval=4)
+    assert ei.value.code == 1
+    with pytest.raises(FwiError):
+        Engine((32, 32), 10.0, 1e-3, 8, npml=4, sigma_max=100.0, abc="cpml", pml_alpha_max=-1.0)
+    with Engine((32, 32), 10.0, 1e-3, 8, npml=0, abc="cpml") as e:  # no border: nothing to absorb with, plain run
+        d = e.forward(np.full((32, 32), 2000.0, np.float32), ([[16, 16]], np.ones(8, np.float32)), [[8, 8]])
+        assert d.shape == (8, 1) and e.kernel_name == "step2d_fused"

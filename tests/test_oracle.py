@@ -246,3 +246,81 @@ def test_observed_convergence_orders():
     # time: fine space, halve dt: order 2 => ratio ~ 4
     e1, e2 = err(48, 0.8), err(48, 0.4)
     assert 2.5 < e1 / e2 < 6.0, (e1, e2)
+
+
+# ---------------------------------------------------------------------------
+# second absorbing boundary: convolutional PML (abc="cpml")
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,order", CASES)
+@pytest.mark.parametrize("alpha", [0.0, 40.0])
+def test_cpml_adjoint_identity(shape, order, alpha):
+    """<F s, r> = <s, F^T r> to round-off: the adjoint sweep is the exact transpose of the CPML recursion,
+    sources and receivers inside the border included."""
+    c, h, dt, src, rec, w, r = _random_case(shape, order)
+    p = fo.Propagator(c, h, dt, order, 5, abc="cpml", pml_alpha_max=alpha)
+    d = p.forward(src, w, rec, save=False)
+    a = p.adjoint(r, image=False)
+    lhs, rhs = float(np.sum(d * r)), float(np.sum(w * a))
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs))
+
+
+@pytest.mark.parametrize("shape,order", [((30, 26), 8), ((14, 12, 16), 4)])
+def test_cpml_gradient_matches_finite_differences(shape, order):
+    c, h, dt, src, rec, w, _ = _random_case(shape, order, nt=60, nsrc=1)
+    w = fo.ricker(60, dt, 0.1 / dt / 4)[:, None]
+    kw = dict(sigma_max=900.0, abc="cpml", pml_alpha_max=30.0)
+
+    def data(cm):
+        p = fo.Propagator(cm, h, dt, order, 5, **kw)
+        return p, p.forward(src, w, rec)
+
+    _, d_obs = data(c * 1.02)
+    p, d = data(c)
+    p.adjoint(d - d_obs)
+    g = p.gradient()
+    dc = np.random.default_rng(3).standard_normal(shape)
+    eps = 1e-3
+    Jp = 0.5 * np.sum((data(c + eps * dc)[1] - d_obs) ** 2)
+    Jm = 0.5 * np.sum((data(c - eps * dc)[1] - d_obs) ** 2)
+    fd = (Jp - Jm) / (2 * eps)
+    assert abs(fd - np.sum(g * dc)) <= 1e-6 * abs(fd)
+
+
+def test_cpml_reflects_far_less_than_the_sponge_at_equal_width():
+    """Homogeneous 2-D medium, 10-cell border: seismograms near the border against a run on a grid so large that
+    nothing comes back within the window.  The sponge leaves tens of per cent, the CPML a few 1e-4 (alpha = 0)."""
+    h, order, c0, n, big, npml, f0 = 10.0, 8, 2000.0, 80, 260, 10, 12.0
+    dt = 0.7 * fo.cfl_dt(c0, h, 2, order)
+    nt = 380
+    w = fo.ricker(nt, dt, f0)
+
+    def run(nn, abc, width, alpha=0.0):
+        off = (nn - n) // 2
+        p = fo.Propagator(np.full((nn, nn), c0), h, dt, order, width, abc=abc, pml_alpha_max=alpha)
+        rec = np.array([[off + npml + 2, off + x] for x in range(npml + 2, n - npml - 2, 4)])
+        return p.forward(np.array([[off + n // 2, off + n // 2]]), w, rec, save=False)
+
+    ref = run(big, "sponge", 0)
+    e_sponge = rel(run(n, "sponge", npml), ref)
+    e_cpml = rel(run(n, "cpml", npml), ref)
+    e_cpml_a = rel(run(n, "cpml", npml, np.pi * f0), ref)
+    assert e_sponge > 0.05 and e_cpml < 2e-3 and e_cpml_a < 1e-2 and e_cpml < e_sponge / 50
+
+
+def test_cpml_is_stable_over_many_steps():
+    c0, h, order = 2000.0, 10.0, 8
+    dt = 0.7 * fo.cfl_dt(c0, h, 2, order)
+    p = CPropagator(np.full((48, 48), c0), h, dt, order, 8, abc="cpml", pml_alpha_max=np.pi * 12.0)
+    d = p.forward(np.array([[24, 24]]), fo.ricker(4000, dt, 12.0), np.array([[10, 24]]), save=False)
+    assert np.isfinite(d).all() and np.abs(d[-300:]).max() < 1e-4 * np.abs(d).max()
+
+
+@pytest.mark.parametrize("shape,order", [((30, 26), 8), ((30, 26), 2), ((14, 12, 16), 8), ((9, 40), 4)])
+def test_c_oracle_cpml_matches_numpy_oracle(shape, order):
+    """... including a grid thinner than two borders ((9, 40) with npml = 5: the borders overlap)."""
+    c, h, dt, src, rec, w, r = _random_case(shape, order)
+    kw = dict(abc="cpml", pml_alpha_max=25.0)
+    p, q = fo.Propagator(c, h, dt, order, 5, **kw), CPropagator(c, h, dt, order, 5, **kw)
+    assert rel(q.forward(src, w, rec), p.forward(src, w, rec)) < 1e-12
+    assert rel(q.adjoint(r), p.adjoint(r)) < 1e-12
+    assert rel(q.gradient(), p.gradient()) < 1e-12
