@@ -57,6 +57,9 @@ struct fwi_ctx {
     void *u[2] = {nullptr, nullptr};  // padded wavefields (ping-pong)
     bool inc = false;                 // increment form: state (u, v = u - u_prev); u[] ping-pongs u, v lives in vf
     void *vf = nullptr, *fwv = nullptr;  // v of the running sweep / of the checkpointed forward recomputation
+    // 3-D temporal blocking (fwi_pair3d.hip): forward sweeps without imaging advance two steps per pass
+    bool pair3d = false;
+    int pair_zc = 0, pair_tw = 256;
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
@@ -94,6 +97,9 @@ struct fwi_ctx {
              *fi_cidx = nullptr, *fi_cu = nullptr, *fi_cq = nullptr;
         void *fr_start = nullptr, *fr_lz = nullptr, *fr_lx = nullptr, *fr_col = nullptr;
         size_t fcap = 0, fcap_start = 0;
+        // entries of the 3-D two-step kernel, CSR over its workgroups
+        void *pr_start = nullptr, *pr_ent = nullptr;
+        size_t pcap = 0, pcap_start = 0;
     } src, rec;
     void *wav = nullptr;     // (nt, nsrc) source wavelets of the last forward (kept for recomputation)
     void *amp = nullptr;     // (nt, nrec) residual being back-propagated
@@ -525,9 +531,114 @@ struct Impl {
             HIPCHK(ctx, up(ps.fr_lx, rlx.data(), rlx.size() * sizeof(int)));
             HIPCHK(ctx, up(ps.fr_col, rcol.data(), rcol.size() * sizeof(int)));
         }
+        std::vector<int> pst;
+        std::vector<Pair3dInj> pent;
+        if (ctx->pair3d) {
+            if constexpr (std::is_same<T, float>::value) {
+                // a point is injected by every workgroup whose step-1 region (tile widened by r) holds it
+                const int zc = ctx->pair_zc, tw = ctx->pair_tw, r = g.r, TYI = PAIR3D_TY;
+                const int nxt = g.nx <= 256 ? 1 : (g.nx + tw - 1) / tw;
+                const int nyt = (g.ny + TYI - 1) / TYI, nzc = (g.nz + zc - 1) / zc;
+                const int ntile = nxt * nyt * nzc;
+                std::vector<std::vector<Pair3dInj>> per(ntile);
+                for (int i = 0; i < n; ++i) {
+                    const int z = idx[(size_t)i * 3], y = idx[(size_t)i * 3 + 1], x = idx[(size_t)i * 3 + 2];
+                    for (int bz = std::max(0, (z - r) / zc - 1); bz < nzc; ++bz) {
+                        const int z0 = bz * zc, z1 = std::min(g.nz, z0 + zc);
+                        if (z < z0 - r || z >= z1 + r) continue;
+                        for (int by = std::max(0, (y - r) / TYI - 1); by < nyt; ++by) {
+                            const int y0 = by * TYI;
+                            if (y < y0 - r || y >= y0 + TYI + r) continue;
+                            for (int bx = 0; bx < nxt; ++bx) {
+                                const int xi0 = bx * tw, xbase = nxt == 1 ? 0 : xi0 - 2 * HALO;
+                                if (nxt > 1 && (x < xi0 - r || x >= xi0 + tw + r)) continue;
+                                const bool own = z >= z0 && z < z1 && y >= y0 && y < y0 + TYI &&
+                                                 (nxt == 1 || (x >= xi0 && x < xi0 + tw));
+                                per[(bz * nyt + by) * nxt + bx].push_back(
+                                    Pair3dInj{z, y - y0, x - xbase, i, (float)cu[i], own ? 1 : 0});
+                            }
+                        }
+                    }
+                }
+                pst.assign(ntile + 1, 0);
+                for (int k = 0; k < ntile; ++k) {
+                    pst[k + 1] = pst[k] + (int)per[k].size();
+                    pent.insert(pent.end(), per[k].begin(), per[k].end());
+                }
+                const size_t sb = pst.size() * sizeof(int), eb = pent.size() * sizeof(Pair3dInj) + 16;
+                if (ps.pcap_start < sb) {
+                    if (ps.pr_start) HIPCHK(ctx, hipFree(ps.pr_start));
+                    ps.pr_start = nullptr;
+                    HIPCHK(ctx, hipMalloc(&ps.pr_start, sb));
+                    ps.pcap_start = sb;
+                }
+                if (ps.pcap < eb) {
+                    if (ps.pr_ent) HIPCHK(ctx, hipFree(ps.pr_ent));
+                    ps.pr_ent = nullptr;
+                    HIPCHK(ctx, hipMalloc(&ps.pr_ent, eb));
+                    ps.pcap = eb;
+                }
+                HIPCHK(ctx, up(ps.pr_start, pst.data(), sb));
+                HIPCHK(ctx, up(ps.pr_ent, pent.data(), pent.size() * sizeof(Pair3dInj)));
+            }
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
         ps.n = n;
         return FWI_OK;
+    }
+
+    // 3-D temporal blocking: `count` (even) forward steps from n0, two per pass, ping-ponging between the buffer
+    // pair in `sw` and `spare`.  Both new fields are sampled by the next pass; the last pair by the caller's
+    // flush_record (newest field) and one explicit record here (the older one).
+    static int run_pairs(fwi_ctx *ctx, Sweep &sw, void **spare, int n0, int count, const fwi_ctx::PointSet &inj,
+                         const T *amp, const fwi_ctx::PointSet *out, T *series, T out_scale) {
+        if constexpr (std::is_same<T, float>::value) {
+            const GridDesc &g = ctx->gd;
+            const StepArgs<T> b = base_args(ctx, 0);
+            for (int done = 0; done < count; done += 2) {
+                const int n = n0 + done;
+                Pair3dArgs a{};
+                a.u_cur = (const float *)sw.f[sw.cur];
+                a.u_prev = (const float *)sw.f[sw.cur ^ 1];
+                a.C = (const float *)ctx->C;
+                a.out2 = (float *)spare[0];
+                a.out1 = (float *)spare[1];
+                a.dy = (const float *)ctx->dy;
+                a.dx = (const float *)ctx->dx;
+                for (int k = 0; k < 5; ++k) a.ck[k] = b.ck[k];
+                a.damp = b.damp;
+                a.npml = b.npml;
+                a.dz_scale = b.dz_scale;
+                if (inj.n > 0) {
+                    a.inj_start = (const int *)inj.pr_start;
+                    a.inj = (const Pair3dInj *)inj.pr_ent;
+                    a.inj_amp0 = amp + (size_t)n * inj.n;
+                    a.inj_amp1 = amp + (size_t)(n + 1) * inj.n;
+                }
+                if (out && out->n > 0 && done > 0) {  // the previous pass' fields: steps n - 2 and n - 1
+                    a.rec_pidx = (const int64_t *)out->pidx;
+                    a.rec_out0 = series + (size_t)(n - 2) * out->n;
+                    a.rec_out1 = series + (size_t)(n - 1) * out->n;
+                    a.rec_scale = out_scale;
+                    a.nrec = out->n;
+                }
+                HIPCHK(ctx, launch_pair3d(g, a, ctx->pair_zc, ctx->pair_tw, ctx->stream));
+                void *oc = sw.f[sw.cur], *op = sw.f[sw.cur ^ 1];
+                sw.f[0] = spare[0];  // u^{n+2}
+                sw.f[1] = spare[1];  // u^{n+1}
+                sw.cur = 0;
+                spare[0] = oc;
+                spare[1] = op;
+            }
+            if (out && out->n > 0 && count > 0)
+                HIPCHK(ctx, launch_record<T>((const T *)sw.f[1], (const int64_t *)out->pidx,
+                                             series + (size_t)(n0 + count - 2) * out->n, out_scale, out->n, ctx->stream));
+            sw.prev_n = count > 0 ? n0 + count - 1 : sw.prev_n;
+            return FWI_OK;
+        } else {
+            (void)sw; (void)spare; (void)n0; (void)count; (void)inj; (void)amp; (void)out; (void)series; (void)out_scale;
+            return ctx->fail(FWI_ESTATE, "3-D two-step path is fp32 only");
+        }
     }
 
     // 2-D temporal blocking: `count` steps (a multiple of FUSED2D_STEPS) starting at n0 in direction
@@ -756,9 +867,18 @@ struct Impl {
         // a step count that is not a multiple of FUSED2D_STEPS: the bulk fused, the last 1-3 steps one per launch
         const int nfused = mixed_fused_steps(ctx, nt);
         void *spare[2] = {ctx->fx[0], ctx->fx[1]};
-        if ((fused || nfused) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
+        // 3-D: a forward sweep that keeps nothing for imaging runs two time steps per pass (the last step of an
+        // odd count goes through the single-step kernel)
+        const int npair = (ctx->pair3d && !save && base_args(ctx, 0).damp == 0) ? (nt & ~1) : 0;
+        if ((fused || nfused || npair) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
-        if (save && K > 0) {
+        if (npair) {
+            if ((rc = run_pairs(ctx, sw, spare, 0, npair, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1))))
+                return rc;
+            if ((rc = run_steps(ctx, sw, npair, 1, nt - npair, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1),
+                                none, noq)))
+                return rc;
+        } else if (save && K > 0) {
             for (int n0 = 0, seg = 0; n0 < nt; n0 += K, ++seg) {
                 T *sn = (T *)ctx->snap + (size_t)seg * 2 * g.ptot;  // (u^n0, u^{n0-1})
                 HIPCHK(ctx, hipMemcpyAsync(sn, sw.f[sw.cur], (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -792,7 +912,7 @@ struct Impl {
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
-        if (fused || nfused) {  // the buffer pairs may have changed roles: keep ownership consistent
+        if (fused || nfused || npair) {  // the buffer pairs may have changed roles: keep ownership consistent
             ctx->u[0] = sw.f[0];
             ctx->u[1] = sw.f[1];
             ctx->fx[0] = spare[0];
@@ -1221,12 +1341,25 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // (the CPML's slab kernels run between time steps: one step per launch, the tile kernel)
     ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml &&
                    !getenv("FWI_NO_FUSED2D");
+    // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
+    // =1 is the tuning / comparison hook)
+    if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {
+        const char *pe = getenv("FWI_STREAM_PAIR");
+        ctx->pair3d = pe ? atoi(pe) != 0 : false;
+        if (ctx->pair3d) {
+            pair3d_default_tuning(ctx->gd, &ctx->pair_zc, &ctx->pair_tw);
+            if (const char *zc = getenv("FWI_PAIR_ZCHUNK")) {
+                const int v = atoi(zc);
+                if (v >= 1) ctx->pair_zc = v;
+            }
+        }
+    }
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
          hipMemset(ctx->vf, 0, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess))
         rc = ctx->fail(FWI_ENOMEM, "allocating the increment field failed");
-    if (rc == FWI_OK && ctx->fused2d) {
+    if (rc == FWI_OK && (ctx->fused2d || ctx->pair3d)) {
         for (int i = 0; i < 2 && rc == FWI_OK; ++i) {
             if (hipMalloc(&ctx->fx[i], (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
                 hipMemset(ctx->fx[i], 0, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess)
@@ -1253,7 +1386,8 @@ void fwi_destroy(fwi_ctx *ctx) {
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
                         ps->s_cq, ps->s_col, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,
-                        ps->fi_cidx, ps->fi_cu, ps->fi_cq, ps->fr_start, ps->fr_lz, ps->fr_lx, ps->fr_col})
+                        ps->fi_cidx, ps->fi_cu, ps->fi_cq, ps->fr_start, ps->fr_lz, ps->fr_lx, ps->fr_col, ps->pr_start,
+                        ps->pr_ent})
             if (p) (void)hipFree(p);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

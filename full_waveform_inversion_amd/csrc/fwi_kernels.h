@@ -169,6 +169,34 @@ struct Fused2dArgs {
 int fused2d_num_tiles(const GridDesc &g);
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
 
+// ---- 3-D temporal blocking (fwi_pair3d.hip): two time steps per pass, fp32, forward sweeps without imaging ----
+constexpr int PAIR3D_TY = 8;   // interior rows (= waves) per workgroup
+struct Pair3dInj {             // one source term as seen by one workgroup
+    int z, yoff, xoff;         // plane; row relative to the tile's first interior row; column relative to lane 0's
+    int col;                   // column of the amplitude rows
+    float cu;                  // coefficient of the amplitude in u
+    int interior;              // the point is one of the workgroup's own (then step 2 injects it too)
+};
+struct Pair3dArgs {
+    const float *u_cur, *u_prev, *C;   // u^n, u^{n-1}, dt^2 c^2 (padded)
+    float *out1, *out2;                // u^{n+1}, u^{n+2} (another buffer pair)
+    const float *dy, *dx;              // damping profiles (the z one is formed from the plane index)
+    float ck[5];
+    int damp, npml;
+    float dz_scale;
+    const int *inj_start;              // CSR over workgroups (the kernel's renumbered order) into inj
+    const Pair3dInj *inj;
+    const float *inj_amp0, *inj_amp1;  // amplitude rows of step n and n + 1
+    const int64_t *rec_pidx;           // sampling of the previous pass' two fields (u_prev -> out0, u_cur -> out1)
+    float *rec_out0, *rec_out1;
+    float rec_scale;
+    int nrec;
+};
+void pair3d_default_tuning(const GridDesc &g, int *zchunk, int *tw);
+int pair3d_num_tiles(const GridDesc &g, int zchunk, int tw);
+int pair3d_tile_of(const GridDesc &g, int zchunk, int tw, int z, int y, int x);
+hipError_t launch_pair3d(const GridDesc &g, const Pair3dArgs &a, int zchunk, int tw, hipStream_t s);
+
 // optimiser vector algebra: y = a x + b y; clamp; *out = max(*out, max|x|) (out zeroed by the caller)
 template <typename T>
 hipError_t launch_axpby(T *y, double a, const T *x, double b, int64_t n, hipStream_t s);

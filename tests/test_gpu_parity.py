@@ -463,6 +463,38 @@ def test_increment_form_matches_the_oracle(gpu, shape, order, npml, dtype, tol, 
                    update_form="increment", kernel="stream")
 
 
+@pytest.mark.parametrize("shape,order,nt,zc", [
+    ((40, 36, 256), 8, 40, 0),     # one full-row tile per y strip
+    ((40, 36, 256), 8, 41, 16),    # odd step count (last step single), z chunks of 16: sources on chunk seams
+    ((33, 29, 50), 8, 30, 7),      # ragged everything, chunks shorter than the halo stack
+    ((24, 21, 300), 8, 26, 0),     # rows wider than 256 columns: x tiles with their own halo
+    ((30, 28, 36), 4, 30, 0),
+    ((30, 28, 36), 2, 30, 0)])
+def test_two_steps_per_pass_3d_matches_the_oracle(gpu, monkeypatch, shape, order, nt, zc):
+    """3-D temporal blocking (fwi_pair3d.hip): forward sweeps that keep nothing for imaging advance two time
+    steps per pass.  Same arithmetic as the single-step kernel, so the same tolerance -- with sources on tile and
+    chunk seams (every neighbouring workgroup must see the first step's source before its second step) and
+    receivers anywhere."""
+    monkeypatch.setenv("FWI_STREAM_PAIR", "1")
+    if zc:
+        monkeypatch.setenv("FWI_PAIR_ZCHUNK", str(zc))
+    rng = np.random.default_rng(9)
+    c = 2000.0 + 600.0 * rng.random(shape)
+    h = 10.0
+    dt = 0.7 * fo.cfl_dt(c.max(), h, 3, order)
+    nz, ny, nx = shape
+    src = np.array([[nz // 2, ny // 2, nx // 2], [15, 7, 3], [16, 8, nx - 2], [min(nz - 1, 17), 15, nx // 2 + 1],
+                    [0, 0, 0], [nz - 1, ny - 1, nx - 1], [nz // 2, ny // 2, nx // 2]])  # (a duplicate node too)
+    rec = np.stack([rng.integers(0, s, 12) for s in shape], 1)
+    wav = np.stack([fo.ricker(nt, dt, 0.12 / dt / 8) * (1 + 0.2 * k) for k in range(len(src))], 1)
+    d = fo.Propagator(c, h, dt, order, 0).forward(src, wav, rec, save=False)
+    with Engine(shape, h, dt, nt, order=order, npml=0) as e:
+        dg = e.forward(c, (src, wav), rec, save=False)
+        dg2 = e.forward(None, (src, wav), rec, save=True)   # the single-step path of the same context
+    assert rel(dg, d) < TOL32 and rel(dg2, d) < TOL32
+    assert rel(dg, dg2) < 2e-6
+
+
 def test_lbfgs_inversion_on_gpu_reduces_misfit(gpu):
     """cfg5 scaled (3-D, smooth random model): 3 L-BFGS iterations with the GPU dot product."""
     from full_waveform_inversion_amd import shots as sh
