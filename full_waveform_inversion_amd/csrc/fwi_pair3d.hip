@@ -52,12 +52,15 @@ __global__ __launch_bounds__(64 * PAIR3D_TY) void step3d_pair(Pair3dArgs a, Grid
     constexpr int TYI = PAIR3D_TY;          // interior rows per workgroup = waves per workgroup
     constexpr int NQ = 2 * R + 2;           // z-queue slots: planes s-R .. s+R of u^n plus the one in flight
     constexpr int NRING = R + 1;            // planes of u^{n+1} kept in LDS (s-R .. s)
-    constexpr int SROWS = TYI + 4 * R;      // staged rows of u^n
-    constexpr int RROWS = TYI + 2 * R;      // rows of u^{n+1}
+    constexpr int SROWS = TYI + 4 * R;      // staged rows of u^n (+ one trash row behind them)
+    constexpr int RROWS = TYI + 2 * R;      // rows of u^{n+1}    (+ one trash row)
     constexpr int LROW = 66;                // LDS row in float4: [zero edge][64 lanes][zero edge]
     static_assert(NQ % NRING == 0 && NQ % 2 == 0, "ring indices must be static under the NQ-fold unrolling");
-    __shared__ f4 stg[2][SROWS][LROW];
-    __shared__ f4 ring[NRING][RROWS][LROW];
+    // The loop body is free of divergent branches (hipcc then counts its s_waitcnt vmcnt(N) exactly and keeps the
+    // next plane's loads in flight across the barrier): waves without a halo row (r < 4) repeat their interior row
+    // and write to the trash rows instead.
+    __shared__ f4 stg[2][SROWS + 1][LROW];
+    __shared__ f4 ring[NRING][RROWS + 1][LROW];
 
     const int lane = threadIdx.x, w = threadIdx.y;
     int bid = blockIdx.x;
@@ -98,17 +101,20 @@ __global__ __launch_bounds__(64 * PAIR3D_TY) void step3d_pair(Pair3dArgs a, Grid
         return g.off0 + (int64_t)y * sy + xc;
     };
     const int64_t pI = rowoff(offI), pH = rowoff(hasH ? offH : offI), pE = rowoff(hasH ? offE : offI);
+    const int srI = offI + 2 * R, srH = hasH ? offH + 2 * R : SROWS, srE = hasH ? offE + 2 * R : SROWS;  // staging rows
+    const int rrI = offI + R, rrH = hasH ? offH + R : RROWS;                                              // ring rows
+    const int lrH = hasH ? srH : srI;  // the row a halo-less wave recomputes (its own interior row, result discarded)
     const bool storeI = in_x && (y0 + offI) < g.ny;
     auto plane = [&](int p) -> int64_t { return (int64_t)min(max(p, -1), g.nz) * sz; };  // clamped to a zero plane
 
     // zero edge vectors of every LDS row (never written afterwards)
-    for (int i = w * 64 + lane; i < 2 * SROWS * 2 + NRING * RROWS * 2; i += 64 * TYI) {
+    for (int i = w * 64 + lane; i < 2 * (SROWS + 1) * 2 + NRING * (RROWS + 1) * 2; i += 64 * TYI) {
         const f4 zero = {{0.f, 0.f, 0.f, 0.f}};
-        if (i < 2 * SROWS * 2) {
-            stg[i / (SROWS * 2)][(i / 2) % SROWS][(i & 1) ? LROW - 1 : 0] = zero;
+        if (i < 2 * (SROWS + 1) * 2) {
+            stg[i / ((SROWS + 1) * 2)][(i / 2) % (SROWS + 1)][(i & 1) ? LROW - 1 : 0] = zero;
         } else {
-            const int k = i - 2 * SROWS * 2;
-            ring[k / (RROWS * 2)][(k / 2) % RROWS][(k & 1) ? LROW - 1 : 0] = zero;
+            const int k = i - 2 * (SROWS + 1) * 2;
+            ring[k / ((RROWS + 1) * 2)][(k / 2) % (RROWS + 1)][(k & 1) ? LROW - 1 : 0] = zero;
         }
     }
 
@@ -144,14 +150,12 @@ __global__ __launch_bounds__(64 * PAIR3D_TY) void step3d_pair(Pair3dArgs a, Grid
     }
 #pragma unroll
     for (int k = 0; k < NQ; ++k) q1I[k] = f4{{0.f, 0.f, 0.f, 0.f}};
-    // The outer halo rows of u^n are only ever staged: they go from HBM / L2 straight into the LDS image
-    // (global_load_lds_dwordx4: destination = wave-uniform row base + lane x 16 B), no registers.
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    f4 upI[2], upH[2], cH[2], cring[NRING], cnext;
+    // (LDS-DMA for the outer halo rows, which are only ever staged, was tried: with a global_load_lds in flight hipcc
+    // drains every outstanding load at the barrier -- 55 instead of 40 us per step)
+    f4 e2[2], upI[2], upH[2], cH[2], cring[NRING], cnext;
     {
         const int64_t o = plane(s0);
-        if (hasH) __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_cur + o + pE), (lptr_t *)&stg[0][offE + 2 * R][1], 16, 0, 0);
+        e2[0] = ld4(a.u_cur + o + pE);
         upI[0] = ld4(a.u_prev + o + pI);
         upH[0] = ld4(a.u_prev + o + pH);
         cH[0] = ld4(a.C + o + pH);
@@ -220,39 +224,37 @@ __global__ __launch_bounds__(64 * PAIR3D_TY) void step3d_pair(Pair3dArgs a, Grid
             f4(*S)[LROW] = stg[cur];
             // ---- stage the u^n rows of plane s --------------------------------------------------------------
             const f4 ctrI = qnI[(ph + R) % NQ], ctrH = qnH[(ph + R) % NQ];
-            S[offI + 2 * R][1 + lane] = ctrI;
-            if (hasH) S[offH + 2 * R][1 + lane] = ctrH;  // (the outer halo row arrived by LDS-DMA)
+            S[srI][1 + lane] = ctrI;
+            S[srH][1 + lane] = ctrH;
+            S[srE][1 + lane] = e2[cur];
             // ---- prefetch plane s + 1 (queue: plane s + R + 1) ------------------------------------------------
             {
                 const int64_t oq = plane(s + R + 1), on = plane(s + 1);
                 qnI[(ph + 2 * R + 1) % NQ] = ld4(a.u_cur + oq + pI);
                 qnH[(ph + 2 * R + 1) % NQ] = ld4(a.u_cur + oq + pH);
+                e2[nxt] = ld4(a.u_cur + on + pE);
                 upI[nxt] = ld4(a.u_prev + on + pI);
                 upH[nxt] = ld4(a.u_prev + on + pH);
                 cH[nxt] = ld4(a.C + on + pH);
                 cnext = ld4(a.C + on + pI);
             }
             __syncthreads();
-            // every wave has left iteration s - 1: its staging buffer is free for plane s + 1's outer halo row
-            if (hasH)
-                __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_cur + plane(s + 1) + pE),
-                                                 (lptr_t *)&stg[nxt][offE + 2 * R][1], 16, 0, 0);
             // ---- stage 1: u^{n+1}(s) on the interior row and the halo row ----------------------------------------
             const float dz1 = DAMP ? dz_of(s) : 0.f;
             f4(*Rg)[LROW] = ring[ph % NRING];
             {
-                const f4 lap = laplace(ctrI, S, offI + 2 * R, [&](int k) -> const f4 & { return qnI[(ph + R + k) % NQ]; });
+                const f4 lap = laplace(ctrI, S, srI, [&](int k) -> const f4 & { return qnI[(ph + R + k) % NQ]; });
                 f4 u1 = update(ctrI, upI[cur], cring[ph % NRING], lap, dxyI, dz1);
                 if (e1 > e0) inject(u1, s, offI, 0);
                 q1I[ph] = u1;
-                Rg[offI + R][1 + lane] = u1;
+                Rg[rrI][1 + lane] = u1;
                 if (storeI && s >= z0 && s < z1) st4(a.out1 + (int64_t)s * sz + pI, u1);
             }
-            if (hasH) {
-                const f4 lap = laplace(ctrH, S, offH + 2 * R, [&](int k) -> const f4 & { return qnH[(ph + R + k) % NQ]; });
+            {
+                const f4 lap = laplace(ctrH, S, lrH, [&](int k) -> const f4 & { return qnH[(ph + R + k) % NQ]; });
                 f4 u1 = update(ctrH, upH[cur], cH[cur], lap, dxyH, dz1);
-                if (e1 > e0) inject(u1, s, offH, 0);
-                Rg[offH + R][1 + lane] = u1;
+                if (e1 > e0) inject(u1, s, hasH ? offH : -1000, 0);
+                Rg[rrH][1 + lane] = u1;
             }
             // ---- stage 2: u^{n+2}(z), z = s - R, on the interior row ------------------------------------------
             const int z = s - R;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64 * PAIR3D_TY) void step3d_pair(Pair3dArgs a, Grid
                 // overwritten before the next iteration's barrier)
                 f4(*Rz)[LROW] = ring[(ph + 1) % NRING];  // slot of plane s - R
                 const f4 c1 = q1I[(ph + 2 + R) % NQ];      // u^{n+1}(z): planes s-2R .. s live in slots ph+2 .. ph+2+2R
-                const f4 lap = laplace(c1, Rz, offI + R, [&](int k) -> const f4 & { return q1I[(ph + 2 + R + k) % NQ]; });
+                const f4 lap = laplace(c1, Rz, rrI, [&](int k) -> const f4 & { return q1I[(ph + 2 + R + k) % NQ]; });
                 f4 u2 = update(c1, qnI[ph % NQ], cring[(ph + 1) % NRING], lap, dxyI, DAMP ? dz_of(z) : 0.f);
                 if (e1 > e0) inject(u2, z, offI, 1);
                 if (storeI) st4(a.out2 + (int64_t)z * sz + pI, u2);
