@@ -58,6 +58,8 @@ struct fwi_ctx {
     bool inc = false;                 // increment form: state (u, v = u - u_prev); u[] ping-pongs u, v lives in vf
     void *vf = nullptr, *fwv = nullptr;  // v of the running sweep / of the checkpointed forward recomputation
     // 3-D temporal blocking (fwi_pair3d.hip): forward sweeps without imaging advance two steps per pass
+    bool qbf16 = false;  // forward-term store in bf16 (fp32 3-D stream contexts)
+    size_t qes = 4;      // bytes per stored forward-term element
     bool pair3d = false;
     int pair_zc = 0, pair_tw = 256;
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
@@ -252,6 +254,7 @@ struct Impl {
         a.q_out = nullptr;
         a.q_in = nullptr;
         a.q_in2 = nullptr;
+        a.q_bf16 = ctx->qbf16 ? 1 : 0;
         a.g = (T *)ctx->g_acc;
         const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
@@ -794,7 +797,7 @@ struct Impl {
         if ((rc = upload_points(ctx, nsrc, src_idx, nrec, rec_idx))) return rc;
         if (save && K == 0 && !ctx->q_store) {
             const size_t slots = ((size_t)ctx->cfg.nt_max + ctx->istride - 1) / ctx->istride;
-            const size_t bytes = slots * g.npts * sizeof(T);
+            const size_t bytes = slots * g.npts * ctx->qes;
             size_t fr = 0, tot = 0;
             HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
             if (bytes > fr)
@@ -899,8 +902,8 @@ struct Impl {
                 return rc;
         } else {
             const int ks = ctx->istride;  // q^n is kept for n % ks == 0, in slot n / ks
-            auto qo = [&](int n) -> T * {
-                return (save && n % ks == 0) ? q_store + (size_t)(n / ks) * g.npts : nullptr;
+            auto qo = [&](int n) -> T * {  // (slot addresses in bytes: the store may hold bf16)
+                return (save && n % ks == 0) ? (T *)((char *)q_store + (size_t)(n / ks) * g.npts * ctx->qes) : nullptr;
             };
             if (nfused && (rc = run_fused(ctx, sw, spare, 0, 1, nfused, ctx->src, (const T *)ctx->wav, &ctx->rec, series,
                                           T(1), save ? 1 : 0, q_store)))
@@ -1048,18 +1051,20 @@ struct Impl {
             // at the lower end, (mu^{nfused+1}, q^{nfused}), is the "last pairing" of that run
             const int ks = ctx->istride;
             plan(nt - 1, nfused, [&](int n) -> const T * {
-                return (image && n + 1 < nt && (n + 1) % ks == 0) ? q_store + (size_t)((n + 1) / ks) * g.npts
-                                                                   : nullptr;
+                return (image && n + 1 < nt && (n + 1) % ks == 0)
+                           ? (const T *)((const char *)q_store + (size_t)((n + 1) / ks) * g.npts * ctx->qes)
+                           : nullptr;
             });
             auto qi = [&](int n, const T *&p, const T *&p2) { p = pq[nt - 1 - n]; p2 = pq2[nt - 1 - n]; };
             if ((rc = run_steps(ctx, sw, nt - 1, -1, nt - nfused, ctx->rec, amp, &ctx->src, series, rs, none, qi)))
                 return rc;
-            q0 = (nfused % ks == 0) ? q_store + (size_t)(nfused / ks) * g.npts : nullptr;
+            q0 = (nfused % ks == 0) ? (const T *)((const char *)q_store + (size_t)(nfused / ks) * g.npts * ctx->qes) : nullptr;
             if (nfused) {
                 // ... then the first nfused steps, FUSED2D_STEPS per launch (pairing inside the launch, no lag)
                 if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
                 sw.prev_n = -1;
-                if (image && q0) HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
+                if (image && q0)
+                    HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, ctx->qbf16, s));
                 if ((rc = run_fused(ctx, sw, spare, nfused - 1, -1, nfused, ctx->rec, amp, &ctx->src, series, rs,
                                     image ? 2 : 0, q_store)))
                     return rc;
@@ -1074,7 +1079,14 @@ struct Impl {
         }
         if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
         if (image && !imaged_all)  // the last pairing: mu^1 with q^0
-            HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, s));
+            HIPCHK(ctx, launch_image<T>(g, (const T *)sw.f[sw.cur], q0, (T *)ctx->g_acc, ctx->qbf16, s));
+        if (image && ctx->qbf16 && ctx->nsrc > 0)
+            // the store holds C L u rounded to bf16; the source's own share C w / h^D of the forward term is paired
+            // exactly, in closed form: g(x_s) += cq_s sum_n mu^{n+1}(x_s) w_s^n, with mu at the sources = the series
+            // this sweep has just recorded (scaled by rs)
+            HIPCHK(ctx, launch_source_image<T>((const T *)ctx->series, (const T *)ctx->wav, (const int64_t *)ctx->src.cidx,
+                                               (const T *)ctx->src.cq, (T *)ctx->g_acc, nt, ctx->nsrc, ctx->istride,
+                                               (T)(1.0 / (double)rs), s));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
         return download_series(ctx, adj_src_out, ctx->series,
@@ -1289,6 +1301,10 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->store_dtype == FWI_STORE_BF16 && cfg->dtype != FWI_F32) return bad("store_dtype bf16 needs an fp32 context");
     if (cfg->reserved0 != 0) return bad("reserved0 must be 0");
     if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
+    if (cfg->store_dtype == FWI_STORE_BF16 &&
+        (cfg->ndim != 3 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
+         cfg->update_form != FWI_UPDATE_STANDARD))
+        return bad("store_dtype bf16: 3-D fp32 stream kernel, standard update form, no checkpointing");
     if (cfg->abc == FWI_ABC_CPML && cfg->npml > 0 && cfg->ckpt_interval > 0)
         return bad("abc cpml and ckpt_interval > 0 cannot be combined (the snapshots do not hold the memory variables)");
     int ndev = 0;
@@ -1310,6 +1326,8 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->istride = cfg->image_stride > 1 ? cfg->image_stride : 1;
     ctx->inc = cfg->update_form == FWI_UPDATE_INCREMENT;
     ctx->cpml = cfg->abc == FWI_ABC_CPML && cfg->npml > 0;
+    ctx->qbf16 = cfg->store_dtype == FWI_STORE_BF16;
+    ctx->qes = ctx->qbf16 ? 2 : (cfg->dtype == FWI_F32 ? 4 : 8);
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
         delete ctx;

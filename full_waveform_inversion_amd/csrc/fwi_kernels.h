@@ -46,6 +46,7 @@ struct StepArgs {
     const T *q_in;   // compact forward term to correlate u_cur with, or nullptr
     const T *q_in2;  // second pairing taken in the same launch: u_prev (before it is overwritten) with
                      // this term, so the gradient accumulator is read-modified-written every other step
+    int q_bf16;      // q_out / q_in / q_in2 point at bf16 arrays (fp32 stream kernel only; fwi_config.store_dtype)
     T *g;            // compact gradient accumulator (used with q_in)
     T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
     int damp;        // npml > 0
@@ -99,7 +100,11 @@ template <typename T>
 hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n, hipStream_t s);
 // g[i] += u(center of point i) * q[i] over the whole grid (last imaging step)
 template <typename T>
-hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipStream_t s);
+hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, int q_bf16, hipStream_t s);
+// bf16 store: gacc[cidx[s]] += cq[s] * inv_rs * sum_{n % stride == 0} adj_series[n, s] * wav[n, s]
+template <typename T>
+hipError_t launch_source_image(const T *adj_series, const T *wav, const int64_t *cidx, const T *cq, T *gacc, int nt,
+                               int nsrc, int stride, T inv_rs, hipStream_t s);
 // out[i] = gacc[i] * scale * (wrt_velocity ? -2 / c[i]^3 : 1); 0 in the pad columns
 template <typename T>
 hipError_t launch_finalize_gradient(const GridDesc &g, const T *gacc, const T *c, T *out, double scale,

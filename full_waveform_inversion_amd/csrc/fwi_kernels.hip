@@ -182,6 +182,46 @@ __device__ __forceinline__ void stv_stream(T *p, const vec<T> &f) {
     for (int j = 0; j < VecOf<T>::VL; ++j) v[j] = f.v[j];
     __builtin_nontemporal_store(v, reinterpret_cast<nt_t *>(p));
 }
+// Forward-term store in bf16 (fwi_config.store_dtype): 4 values = 8 bytes per lane, round to nearest even on the
+// way out, exact on the way in.  bf16 keeps fp32's exponent, so the term needs no scaling.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void st_bf16x4_stream(void *base, int64_t elem, const vec<float> &q) {
+    u32x2 w;
+    w[0] = bf16_rne(q.v[0]) | (bf16_rne(q.v[1]) << 16);
+    w[1] = bf16_rne(q.v[2]) | (bf16_rne(q.v[3]) << 16);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(base) + elem));
+}
+__device__ __forceinline__ vec<float> ld_bf16x4_stream(const void *base, int64_t elem) {
+    const u32x2 w = __builtin_nontemporal_load(
+        reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned short *>(base) + elem));
+    vec<float> q;
+    q.v[0] = __uint_as_float(w[0] << 16);
+    q.v[1] = __uint_as_float(w[0] & 0xffff0000u);
+    q.v[2] = __uint_as_float(w[1] << 16);
+    q.v[3] = __uint_as_float(w[1] & 0xffff0000u);
+    return q;
+}
+template <typename T>
+__device__ __forceinline__ void st_q(T *base, int64_t elem, const vec<T> &q, bool) { stv_stream<T>(base + elem, q); }
+template <typename T>
+__device__ __forceinline__ vec<T> ld_q(const T *base, int64_t elem, bool) { return ldv_stream<T>(base + elem); }
+template <bool QB>
+__device__ __forceinline__ void st_qf(float *base, int64_t elem, const vec<float> &q) {
+    if (QB) st_bf16x4_stream(base, elem, q); else stv_stream<float>(base + elem, q);
+}
+template <bool QB>
+__device__ __forceinline__ vec<float> ld_qf(const float *base, int64_t elem) {
+    return QB ? ld_bf16x4_stream(base, elem) : ldv_stream<float>(base + elem);
+}
+template <bool QB>
+__device__ __forceinline__ void st_qf(double *base, int64_t elem, const vec<double> &q) { stv_stream<double>(base + elem, q); }
+template <bool QB>
+__device__ __forceinline__ vec<double> ld_qf(const double *base, int64_t elem) { return ldv_stream<double>(base + elem); }
+
 __device__ __forceinline__ f4 ld4(const float *p) { return ldv<float>(p); }
 __device__ __forceinline__ void st4(float *p, const f4 &v) { stv<float>(p, v); }
 __device__ __forceinline__ f4 ld4_stream(const float *p) { return ldv_stream<float>(p); }
@@ -200,7 +240,8 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 
 // IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
-template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false>
+template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false,
+          bool QB = false>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk, int tw) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -362,8 +403,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             V qi, qi2, gi;
             if (IMAGE) {
                 const unsigned co = act ? coff : 0u;
-                qi = ldv_stream<T>(a.q_in + (int64_t)z * cplane + co);
-                if (IMAGE == 2) qi2 = ldv_stream<T>(a.q_in2 + (int64_t)z * cplane + co);
+                qi = ld_qf<QB>(a.q_in, (int64_t)z * cplane + co);
+                if (IMAGE == 2) qi2 = ld_qf<QB>(a.q_in2, (int64_t)z * cplane + co);
                 // g is touched once per (other) step: streaming hints keep it from evicting the three
                 // wavefield arrays from the Infinity Cache (adjoint 68 -> 59 us/step at 256^3)
                 gi = ldv_stream<T>(a.g + (int64_t)z * cplane + co);
@@ -430,7 +471,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             if (act) {
                 if (INC) stv<T>(a.v + (int64_t)z * sz + poff, vn);
                 stv<T>(a.u_prev + (int64_t)z * sz + poff, un);
-                if (SAVE_Q) stv_stream<T>(a.q_out + (int64_t)z * cplane + coff, q);
+                if (SAVE_Q) st_qf<QB>(a.q_out, (int64_t)z * cplane + coff, q);
                 if (IMAGE) {
 #pragma unroll
                     for (int j = 0; j < VL; ++j) {
@@ -454,7 +495,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                 const T amp = a.inj_amp[a.inj_col[i]];
                 atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
                 if (INC) atomicAdd(a.v + a.inj_pidx[i], a.inj_cu[i] * amp);  // the source moves u' and v' alike
-                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
+                // (bf16 store: the source's own share of the imaging term is added in closed form after the adjoint
+                // sweep, source_image_kernel, instead of being rounded into the store)
+                if (SAVE_Q && !QB) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
             }
         }
     }
@@ -658,6 +701,20 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
             return hipGetLastError();
         }
     }
+    if constexpr (std::is_same<T, float>::value) {
+        if (a.q_bf16 && (a.q_out || a.q_in)) {  // forward term stored in bf16
+            if (a.q_out)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, true>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else if (a.q_in2)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, true>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, true>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+    }
     if (a.q_out)
         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
                            zchunk, nxt, nyt, nblk, tw);
@@ -839,7 +896,34 @@ hipError_t launch_record(const T *u, const int64_t *pidx, T *out, T scale, int n
 // Imaging tail, gradient scaling, dot product.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void image_kernel(GridDesc g, const T *u, const T *q, T *gacc) {
+__device__ __forceinline__ T q_elem(const T *q, int64_t i, int bf16) {
+    if (bf16) return (T)__uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(q)[i] << 16);
+    return q[i];
+}
+
+// g[x_s] += sum_n mu^{n+1}(x_s) * cq_s * w^n_s: the part of the imaging term that is the source itself (bf16 store)
+template <typename T>
+__global__ void source_image_kernel(const T *adj_series, const T *wav, const int64_t *cidx, const T *cq, T *gacc,
+                                    int nt, int nsrc, int stride, T inv_rs) {
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nsrc) return;
+    double acc = 0.0;
+    for (int n = 0; n < nt; n += stride)
+        acc += (double)adj_series[(int64_t)n * nsrc + sidx] * (double)wav[(int64_t)n * nsrc + sidx];
+    atomicAdd(gacc + cidx[sidx], (T)(acc * (double)inv_rs * (double)cq[sidx]));
+}
+
+template <typename T>
+hipError_t launch_source_image(const T *adj_series, const T *wav, const int64_t *cidx, const T *cq, T *gacc, int nt,
+                               int nsrc, int stride, T inv_rs, hipStream_t s) {
+    if (nsrc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(source_image_kernel<T>, dim3((nsrc + 63) / 64), dim3(64), 0, s, adj_series, wav, cidx, cq, gacc,
+                       nt, nsrc, stride, inv_rs);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void image_kernel(GridDesc g, const T *u, const T *q, T *gacc, int q_bf16) {
     const int64_t rowlen = g.cx;
     for (int64_t ci = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; ci < g.npts;
          ci += (int64_t)gridDim.x * blockDim.x) {
@@ -848,14 +932,14 @@ __global__ void image_kernel(GridDesc g, const T *u, const T *q, T *gacc) {
         if (x >= g.nx) continue;  // pad column of the compact layout
         const int z = (int)(row / g.ny), y = (int)(row % g.ny);
         const int64_t p = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + x;
-        gacc[ci] += u[p] * q[ci];
+        gacc[ci] += u[p] * q_elem<T>(q, ci, q_bf16);
     }
 }
 
 template <typename T>
-hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, hipStream_t s) {
+hipError_t launch_image(const GridDesc &g, const T *u, const T *q, T *gacc, int q_bf16, hipStream_t s) {
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (g.npts + 255) / 256));
-    hipLaunchKernelGGL(image_kernel<T>, dim3(blocks), dim3(256), 0, s, g, u, q, gacc);
+    hipLaunchKernelGGL(image_kernel<T>, dim3(blocks), dim3(256), 0, s, g, u, q, gacc, q_bf16);
     return hipGetLastError();
 }
 
@@ -1028,7 +1112,9 @@ hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
 
 #define FWI_INSTANTIATE(T)                                                                          \
     template hipError_t launch_record<T>(const T *, const int64_t *, T *, T, int, hipStream_t);    \
-    template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, hipStream_t); \
+    template hipError_t launch_image<T>(const GridDesc &, const T *, const T *, T *, int, hipStream_t); \
+    template hipError_t launch_source_image<T>(const T *, const T *, const int64_t *, const T *, T *, int, int, int, T, \
+                                               hipStream_t);                                        \
     template hipError_t launch_finalize_gradient<T>(const GridDesc &, const T *, const T *, T *, double, int, \
                                                     hipStream_t);                                  \
     template hipError_t launch_repack<T>(const GridDesc &, T *, const T *, int, hipStream_t);       \

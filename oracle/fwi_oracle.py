@@ -112,6 +112,13 @@ DCOEFFS = {
 }
 
 
+def bf16_round(x):
+    """fp32 -> bf16 (round to nearest even) -> back, element-wise; returned in the input's dtype."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32).astype(np.asarray(x).dtype)
+
+
 def cpml_profiles(shape, npml, sigma_max, alpha_max, dt):
     """Per-axis 1-D CPML coefficients (a, b); a = 0 outside the npml border."""
     out = []
@@ -140,7 +147,7 @@ class Propagator:
     """fp64 (or any ``dtype``) restatement of one shot's forward/adjoint/gradient."""
 
     def __init__(self, c, h, dt, order=8, npml=0, sigma_max=None, dtype=np.float64, image_stride=1,
-                 abc="sponge", pml_alpha_max=0.0):
+                 abc="sponge", pml_alpha_max=0.0, store_dtype="native"):
         c = np.asarray(c, dtype=np.float64)
         # image_stride S > 1: the imaging condition is a Riemann sum over every S-th step,
         # img = S * sum_{n % S == 0} mu^{n+1} q^n  (the engine's fwi_config.image_stride)
@@ -161,6 +168,9 @@ class Propagator:
         if sigma_max is None:
             sigma_max = default_sigma_max(c.max(), h, npml)
         self.sigma_max = float(sigma_max)
+        # store_dtype="bf16" restates the engine's fwi_config.store_dtype: the stored forward term is C L u rounded
+        # to bf16 (from fp32, nearest even); the source's own share of it is kept exact
+        self.store_bf16 = store_dtype == "bf16"
         if abc not in ("sponge", "cpml"):
             raise ValueError("abc must be 'sponge' or 'cpml'")
         self.abc = abc
@@ -271,12 +281,12 @@ class Propagator:
             src = np.zeros(self.shape, dt_)
             if len(inj_flat):
                 np.add.at(src.reshape(-1), inj_flat, inj_amp[n] * dt_.type(inj_scale))
-            if self.cpml:
-                src = src + self._cpml_term(u_cur, aux, reverse)
-            q = self.C * (self.laplacian(u_cur) + src)
+            extra = self._cpml_term(u_cur, aux, reverse) if self.cpml else 0.0
+            lap = self.laplacian(u_cur) + extra
+            q = self.C * (lap + src)
             u_next = self.A * (2 * u_cur - self.B * u_prev + q)
             if save_q:
-                qs[n] = q
+                qs[n] = (bf16_round(self.C * lap) + self.C * src) if self.store_bf16 else q
             if img is not None and n % self.image_stride == 0:
                 img += self.image_stride * (u_next.astype(np.float64) * image_q[n])
             rec[n] = u_next.reshape(-1)[rec_flat] * dt_.type(rec_scale)
