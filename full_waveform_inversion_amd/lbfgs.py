@@ -1,4 +1,4 @@
-"""L-BFGS (two-loop recursion, Armijo backtracking, box projection) for the model update.
+"""L-BFGS (two-loop recursion, Armijo backtracking + Wolfe-curvature expansion, box projection) for the model update.
 
 The reference has no optimiser (its "optimiser" is exhaustive random search,
 full_waveform_inversion.py:713); BASELINE.json configs[4] asks for 5 L-BFGS
@@ -10,8 +10,13 @@ import numpy as np
 
 
 def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, c1=1e-4, max_ls=8,
-          gtol=0.0, callback=None):
+          gtol=0.0, callback=None, c2=0.9):
     """Minimise ``f`` given ``fg(x) -> (f, g)``.
+
+    Line search: backtracking until the Armijo condition holds; while no backtracking was needed and the slope
+    along the direction is still steeper than ``c2`` times the initial one (the weak Wolfe curvature condition
+    fails: the step is too short, typical of the first, hand-scaled iteration) the step is doubled instead, as
+    long as the misfit keeps decreasing.  ``c2=None`` switches the expansion off (plain Armijo).
 
     ``first_step``: largest change of any component in the first trial step (the gradient of
     an FWI misfit has no natural scale).  ``dot(a, b)``: inner product (pass ``Engine.dot``
@@ -54,17 +59,25 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
             S, Y = [], []
             p = -g * ((first_step if first_step is not None else 1.0) / float(np.abs(g).max()))
             gp = dot(g, p)
-        t = 1.0
+        t, best, shrunk = 1.0, None, False
         for _ in range(max_ls):
             xn = project(x + t * p)
             fn, gn = fg(xn)
             evals += 1
-            if fn <= f + c1 * t * gp:
-                break
-            t *= 0.5
-        else:
+            if fn <= f + c1 * t * gp and (best is None or fn < best[1]):
+                best = (t, fn, xn, gn)
+                if shrunk or c2 is None or not dot(gn, p) < c2 * gp:
+                    break  # Armijo holds and (after backtracking, or by the slope) the step is long enough
+                t *= 2.0   # still descending steeply: the step is too short
+            elif best is not None:
+                break      # the doubled step overshot: keep the last good one
+            else:
+                t *= 0.5
+                shrunk = True
+        if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
             break
+        t, fn, xn, gn = best
         s, y = xn - x, gn - g
         if dot(s, y) > 1e-12 * np.sqrt(dot(s, s) * dot(y, y)):
             S.append(s)
@@ -89,7 +102,7 @@ def _require_finite(f, gmax, gg, it):
 
 
 def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=None, c1=1e-4, max_ls=8,
-                 gtol=0.0, callback=None):
+                 gtol=0.0, callback=None, c2=0.9):
     """The same iteration as :func:`lbfgs` with every model-sized vector resident on the GPU
     (``Engine.vec_*`` slots): per iteration only scalars cross PCIe.
 
@@ -100,11 +113,11 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
     m = int(history)
     if m < 1:
         raise ValueError("history must be >= 1")
-    X, G, XN, GN, P = 0, 1, 2, 3, 4
+    X, G, XN, GN, P, XB, GB = 0, 1, 2, 3, 4, 5, 6  # XB / GB: the best trial point of the line search so far
     # m + 1 pair slots: the candidate pair is formed in a spare slot, so the oldest pair is evicted only
     # once the candidate has passed the curvature test
-    S0, Y0 = 5, 5 + (m + 1)
-    engine.vec_create(5 + 2 * (m + 1))
+    S0, Y0 = 7, 7 + (m + 1)
+    engine.vec_create(7 + 2 * (m + 1))
     engine.vec_upload(X, x0)
     if bounds is not None:
         engine.vec_clip(X, *bounds)
@@ -140,20 +153,32 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
             engine.vec_copy(P, G)
             engine.vec_axpby(P, 0.0, P, (first_step if first_step is not None else 1.0) / gmax)
             gp = -engine.vec_dot(G, P)
-        t = 1.0
-        for _ in range(max_ls):
+        t, best, shrunk = 1.0, None, False
+        for _ in range(max_ls):  # the same search as lbfgs(): Armijo backtracking, Wolfe-curvature expansion
             engine.vec_copy(XN, X)
             engine.vec_axpby(XN, -t, P, 1.0)
             if bounds is not None:
                 engine.vec_clip(XN, *bounds)
             fn = fg(XN, GN)
             evals += 1
-            if fn <= f + c1 * t * gp:
+            if fn <= f + c1 * t * gp and (best is None or fn < best[1]):
+                best = (t, fn)
+                XB, XN = XN, XB
+                GB, GN = GN, GB
+                if shrunk or c2 is None or not -engine.vec_dot(GB, P) < c2 * gp:
+                    break
+                t *= 2.0
+            elif best is not None:
                 break
-            t *= 0.5
-        else:
+            else:
+                t *= 0.5
+                shrunk = True
+        if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
             break
+        t, fn = best
+        XN, XB = XB, XN
+        GN, GB = GB, GN
         k = free.pop(0)  # never empty: at most m of the m + 1 slots hold history
         s, y = S0 + k, Y0 + k
         engine.vec_copy(s, XN)

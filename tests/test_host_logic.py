@@ -189,6 +189,22 @@ def test_lbfgs_quadratic_and_rosenbrock():
     assert f < 1e-8 and np.allclose(x, 1.0, atol=1e-3)
 
 
+def test_lbfgs_expands_a_too_short_first_step():
+    """The first step of an FWI run is scaled by hand (`first_step`); when it is far too short the slope along
+    the direction is still steep at the trial point (weak Wolfe curvature fails) and the search doubles the step
+    instead of accepting it -- and non-finite misfits are an error, not "converged"."""
+    def quad(x):
+        return 0.5 * float(x @ x), x.copy()
+    x0 = np.full(6, 100.0)
+    _, f_w, log_w = lbfgs(quad, x0, maxiter=1, first_step=1e-3, max_ls=30)
+    _, f_a, log_a = lbfgs(quad, x0, maxiter=1, first_step=1e-3, max_ls=30, c2=None)
+    assert log_w[1]["step"] > 1000 * log_a[1]["step"] and f_w < 0.75 * f_a  # (c2 = 0.9: accepted once the slope has dropped 10 %)
+    with pytest.raises(FloatingPointError):
+        lbfgs(lambda x: (float("nan"), x), x0, maxiter=2)
+    with pytest.raises(ValueError):
+        lbfgs(quad, x0, history=0)
+
+
 def test_lbfgs_respects_bounds():
     x, f, _ = lbfgs(lambda x: (float(np.sum((x - 3.0) ** 2)), 2 * (x - 3.0)), np.zeros(4), maxiter=20,
                     first_step=1.0, bounds=(-1.0, 2.0))
