@@ -20,8 +20,9 @@ LEGS = {"headline": 16.0 * 256 ** 3, "hbm": 16.0 * 512 ** 3, "gradient": 22.0 * 
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(SRC, pattern))
-    return hits[0] if hits else None
+    """newest match: gpurun merges a call's outputs INTO gpurun_out/, so an earlier call's files may still be there"""
+    hits = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
+    return hits[-1] if hits else None
 
 
 def main():
