@@ -1303,8 +1303,8 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
     if (cfg->store_dtype == FWI_STORE_BF16 &&
         (cfg->ndim != 3 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
-         cfg->update_form != FWI_UPDATE_STANDARD))
-        return bad("store_dtype bf16: 3-D fp32 stream kernel, standard update form, no checkpointing");
+         cfg->update_form != FWI_UPDATE_STANDARD || (cfg->abc == FWI_ABC_CPML && cfg->npml > 0)))
+        return bad("store_dtype bf16: 3-D fp32 stream kernel, standard update form, sponge border, no checkpointing");
     if (cfg->abc == FWI_ABC_CPML && cfg->npml > 0 && cfg->ckpt_interval > 0)
         return bad("abc cpml and ckpt_interval > 0 cannot be combined (the snapshots do not hold the memory variables)");
     int ndev = 0;

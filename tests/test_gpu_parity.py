@@ -524,7 +524,8 @@ def test_bf16_forward_term_store(gpu, shape, npml, stride):
     assert rel(dg, d) < TOL32
     assert rel(gg, pq.gradient()) < 1e-4
     assert 1e-5 < rel(gg, px.gradient()) < 1e-2
-    for bad in (dict(dtype="float64"), dict(ckpt_interval=8), dict(update_form="increment"), dict(kernel="point")):
+    for bad in (dict(dtype="float64"), dict(ckpt_interval=8), dict(update_form="increment"), dict(kernel="point"),
+                dict(abc="cpml") if npml else dict(dtype="float64")):
         with pytest.raises(FwiError):
             Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=pq.sigma_max, store_dtype="bf16", **bad)
     with pytest.raises(FwiError):
@@ -814,3 +815,52 @@ def test_random_small_configurations_fuzz(gpu):
         assert np.linalg.norm(dg - d) < 2e-5 * scale, tag
         assert np.linalg.norm(ag - a) < 2e-5 * max(np.linalg.norm(a), 1e-300), tag
         assert np.linalg.norm(gg - g) < 5e-5 * max(np.linalg.norm(g), 1e-300), tag
+
+
+def test_random_option_combinations_fuzz(gpu, monkeypatch):
+    """Seeded fuzz over the round-2 options on small odd grids: absorbing border (sponge / CPML with and without
+    alpha), update form (standard / increment), forward-term store (native / bf16 where it applies), checkpointing
+    where it applies, the two-steps-per-pass 3-D kernel for the store-free forward sweep -- forward + adjoint +
+    gradient against the C oracle (the NumPy oracle's restatement for the bf16 store)."""
+    rng = np.random.default_rng(4052)
+    for case in range(36):
+        nd = int(rng.integers(2, 4))
+        order = int(rng.choice([2, 4, 8]))
+        shape = tuple(int(rng.integers(6, 37)) for _ in range(nd))
+        if rng.random() < 0.5:
+            shape = shape[:-1] + (4 * int(rng.integers(2, 12)),)
+        npml = int(rng.integers(0, max(1, min(shape) // 2)))
+        nt = int(rng.choice([7, 8, 13, 16, 22]))
+        c = 1500.0 + 2000.0 * rng.random(shape)
+        h = 6.0
+        dt = 0.6 * fo.cfl_dt(c.max(), h, nd, order)
+        nsrc, nrec = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+        src = np.stack([rng.integers(0, s, nsrc) for s in shape], 1)
+        rec = np.stack([rng.integers(0, s, nrec) for s in shape], 1)
+        w = rng.standard_normal((nt, nsrc))
+        r = rng.standard_normal((nt, nrec))
+        abc = str(rng.choice(["sponge", "cpml"]))
+        alpha = float(rng.choice([0.0, 25.0])) if abc == "cpml" else 0.0
+        form = str(rng.choice(["standard", "increment"]))
+        bf16 = nd == 3 and form == "standard" and (abc == "sponge" or npml == 0) and rng.random() < 0.4
+        ck = int(rng.choice([0, 0, 5])) if (abc == "sponge" or npml == 0) and not bf16 else 0
+        pair = nd == 3 and rng.random() < 0.5
+        monkeypatch.setenv("FWI_STREAM_PAIR", "1" if pair else "0")
+        kw = dict(abc=abc, pml_alpha_max=alpha)
+        if bf16:
+            p = fo.Propagator(c, h, dt, order, npml, store_dtype="bf16", **kw)
+        else:
+            p = CPropagator(c, h, dt, order, npml, **kw)
+        d = p.forward(src, w, rec)
+        a = p.adjoint(r)
+        g = p.gradient()
+        with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, ckpt_interval=ck,
+                    update_form=form, store_dtype="bf16" if bf16 else "native", **kw) as e:
+            d0 = e.forward(c, (src, w), rec, save=False)   # (3-D, no border: the two-step kernel when enabled)
+            dg = e.forward(None, (src, w), rec, save=True)
+            ag = e.adjoint(r)
+            gg = e.gradient()
+            kern = e.kernel_name
+        tag = (case, shape, order, npml, nt, abc, alpha, form, bf16, ck, pair, kern)
+        for x, ref, tol in ((d0, d, 2e-5), (dg, d, 2e-5), (ag, a, 2e-5), (gg, g, 2e-4 if bf16 else 5e-5)):
+            assert np.linalg.norm(x - ref) < tol * max(np.linalg.norm(ref), 1e-300), tag
