@@ -152,8 +152,13 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
                                                    compare_all_waveforms_simultaneously=True, MTs=None,
                                                    seed=0, device=0, reference_stream=False,
                                                    return_absolute_similarity_values_switch=True,
-                                                   sampler="device"):
+                                                   sampler="device",
+                                                   invert_for_ratio_of_multiple_media_greens_func_switch=False,
+                                                   green_func_phase_labels=(), num_phase_types_for_media_ratios=0):
     """The reference's driver (:786-870) with the sample loop on the GPU.
+
+    With ``invert_for_ratio_of_multiple_media_greens_func_switch`` the call is
+    :func:`perform_monte_carlo_sampled_waveform_inversion_multiple_media` (Green's functions ``(k, n, t, 2)``).
 
     ``inversion_type`` is any of the reference's seven (:740-760): ``full_mt``, ``DC``,
     ``single_force``, ``DC_single_force_couple``, ``DC_single_force_no_coupling``,
@@ -171,6 +176,11 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
     """
     if sampler not in ("device", "host"):
         raise ValueError("sampler must be 'device' or 'host'")
+    if invert_for_ratio_of_multiple_media_greens_func_switch:
+        return perform_monte_carlo_sampled_waveform_inversion_multiple_media(
+            real_data_array, green_func_array, num_samples, M_amplitude, inversion_type, comparison_metric,
+            perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously, green_func_phase_labels,
+            num_phase_types_for_media_ratios, seed, device, reference_stream, return_absolute_similarity_values_switch)
     frac = None
     if MTs is None and sampler == "device" and not reference_stream:
         MTs, frac, _, like, post = invert_on_device(
@@ -189,6 +199,82 @@ def perform_monte_carlo_sampled_waveform_inversion(real_data_array, green_func_a
                                   compare_all_waveforms_simultaneously, device)
     if frac is not None:
         MTs = np.vstack((MTs, frac))
+    return MTs, post, (like if return_absolute_similarity_values_switch else [])
+
+
+PHASE_CLASSES = ("P", "S", "surface")  # the reference's three phase types (:718-720)
+
+
+def mixed_media_problem(green_func_array_both_media, frac_medium_2, green_func_phase_labels=None):
+    """The two-media mixture of the worker (:715-731) as ONE linear problem the scoring kernel already solves.
+
+    Per sample the reference scores ``G = (1 - f) G_medium1 + f G_medium2`` -- with one fraction ``f`` for all traces,
+    or (``num_phase_types_for_media_ratios > 0``) one per phase type, every trace taking the fraction of its label.
+    The mixture is linear in the source, so with the Green's functions laid side by side, ``[G_1 | G_2]`` per phase
+    class, the sample ``M`` with fractions ``f_p`` becomes the source ``[(1 - f_p) M ; f_p M]_p`` of an enlarged
+    problem with ``2 n`` (one fraction) or ``6 n`` (three phase classes) components.  Returns
+    ``(G_ext (k, n_ext, t), expand)`` with ``expand(MTs (n, N)) -> (n_ext, N)``.
+    """
+    G2 = _f64(green_func_array_both_media)
+    if G2.ndim != 4 or G2.shape[3] != 2:
+        raise ValueError("two-media Green's functions must be (k, n, t, 2)")
+    k, n, t, _ = G2.shape
+    f = _f64(frac_medium_2)
+    if f.ndim == 1:  # one fraction per sample
+        G_ext = np.concatenate((G2[..., 0], G2[..., 1]), axis=1)
+        return G_ext, lambda M: np.vstack(((1.0 - f)[None, :] * M, f[None, :] * M))
+    labels = list(green_func_phase_labels or [])
+    if len(labels) != k or any(lab not in PHASE_CLASSES for lab in labels):
+        raise ValueError("green_func_phase_labels must hold one of %s per trace" % (PHASE_CLASSES,))
+    G_ext = np.zeros((k, 6 * n, t))
+    for j, lab in enumerate(labels):
+        c = PHASE_CLASSES.index(lab)
+        G_ext[j, 2 * n * c:2 * n * c + n] = G2[j, :, :, 0]
+        G_ext[j, 2 * n * c + n:2 * n * (c + 1)] = G2[j, :, :, 1]
+
+    def expand(M):
+        return np.vstack([blk for c in range(3) for blk in ((1.0 - f[:, c])[None, :] * M, f[:, c][None, :] * M)])
+    return G_ext, expand
+
+
+def perform_monte_carlo_sampled_waveform_inversion_multiple_media(
+        real_data_array, green_func_array, num_samples=1000, M_amplitude=1.0, inversion_type="full_mt",
+        comparison_metric="CC", perform_normallised_waveform_inversion=True,
+        compare_all_waveforms_simultaneously=True, green_func_phase_labels=(), num_phase_types_for_media_ratios=0,
+        seed=0, device=0, reference_stream=False, return_absolute_similarity_values_switch=True):
+    """The driver with ``invert_for_ratio_of_multiple_media_greens_func_switch`` on (:786-870, worker :715-731):
+    ``green_func_array`` is ``(k, n, t, 2)``, every sample also draws the fraction of medium 2 -- one per sample,
+    or one per phase type (P, S, surface) -- and the fractions are appended to ``MTs`` as extra rows (:855-864).
+
+    The sample loop is the same GPU scoring call on the enlarged linear problem of :func:`mixed_media_problem`.
+    The reference's one-fraction branch overwrites its own Green's functions after the first sample (:731, SURVEY
+    Appendix A-8) and cannot run past it; what is implemented is its evident intent, a fresh mixture per sample.
+    ``reference_stream=True`` draws fractions and samples from the global ``numpy.random`` / ``random`` generators in
+    the reference's per-sample order (fractions first, :718-720 / :730).
+    """
+    n_frac = 3 if num_phase_types_for_media_ratios > 0 else 1
+    N = int(num_samples)
+    frac = None
+    if reference_stream:
+        fr, cols, fracs = np.empty((N, n_frac)), [], []
+        for i in range(N):
+            fr[i] = [np.random.uniform(0.0, 1.0) for _ in range(n_frac)]
+            M1, f1 = samplers.draw(inversion_type, 1, None, True)
+            cols.append(M1)
+            fracs.append(f1)
+        MTs = np.hstack(cols) * M_amplitude
+        frac = np.concatenate(fracs) if fracs[0] is not None else None
+    else:
+        rng = np.random.default_rng(seed)
+        fr = rng.uniform(0.0, 1.0, (N, n_frac))
+        MTs, frac = samplers.draw(inversion_type, N, rng, False)
+        MTs = MTs * M_amplitude
+    G_ext, expand = mixed_media_problem(green_func_array, fr if n_frac == 3 else fr[:, 0], green_func_phase_labels)
+    _, like, post = score_samples(real_data_array, G_ext, expand(_f64(MTs)), comparison_metric,
+                                  perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously, device)
+    if inversion_type in samplers.COUPLED_TYPES:
+        MTs = np.vstack((MTs, frac))
+    MTs = np.vstack([MTs] + [fr[:, c] for c in range(n_frac)])  # :855-864
     return MTs, post, (like if return_absolute_similarity_values_switch else [])
 
 

@@ -80,6 +80,16 @@ def compare_synth_to_real_waveforms(real, synth, metric, normalise=True, all_at_
     return float(np.average([f(real[k, :], synth[k, :]) for k in range(real.shape[0])]))
 
 
+def mixed_media_greens(G2, frac_by_phase, labels):
+    """Per-sample Green's functions of the two-media branch with one fraction per phase type (:715-727):
+    trace j takes (1 - f) G[j, :, :, 0] + f G[j, :, :, 1] with f the fraction of its phase label."""
+    G = np.zeros(G2[:, :, :, 0].shape, dtype=float)
+    for j in range(len(labels)):
+        f = frac_by_phase[labels[j]]
+        G[j, :, :] = (1.0 - f) * G2[j, :, :, 0] + f * G2[j, :, :, 1]
+    return G
+
+
 def likelihood(similarity):
     """exp(-(1 - s) / 2)   (:774)."""
     return np.exp(-(1.0 - np.asarray(similarity, float)) / 2.0)

@@ -174,6 +174,36 @@ def samplers_case(ref, name, nsamp=48, ndrv=40):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def multimedia_case(ref, name, nsamp=24):
+    """The worker's two-media branch with one fraction per phase type (:715-727; the one-fraction branch, :730-731,
+    cannot run past its first sample: it overwrites its own Green's functions): Green's
+    functions (k, n, t, 2), phase labels per trace, the driver's three extra fraction rows (:855-861)."""
+    ref.multiprocessing = _InProcess
+    out = {}
+    for typ, n in (("full_mt", 6), ("DC_single_force_couple", 9)):
+        k, t = 5, 48
+        G0, d, _ = make_inputs(300 + n, k, n, t)
+        G1 = make_inputs(400 + n, k, n, t)[0]
+        G2 = np.stack((G0, 0.7 * G0 + 0.6 * G1), axis=3)
+        labels = ["P", "S", "surface", "P", "S"]
+        seed = 9000 + n
+        np.random.seed(seed)
+        random.seed(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            MTs, MTp, MTp_abs = ref.perform_monte_carlo_sampled_waveform_inversion(
+                d, G2, num_samples=nsamp, M_amplitude=0.9, inversion_type=typ, comparison_metric="VR",
+                perform_normallised_waveform_inversion=False, compare_all_waveforms_simultaneously=False,
+                num_processors=1, return_absolute_similarity_values_switch=True,
+                invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_phase_labels=labels,
+                num_phase_types_for_media_ratios=3)
+        out["seed_" + typ], out["G2_" + typ], out["d_" + typ] = seed, G2, d
+        out["labels"] = np.array(labels)
+        out["MTs_" + typ], out["MTp_" + typ], out["MTp_absolute_" + typ] = MTs, MTp, MTp_abs
+        print("multi-media", typ, "MTs", MTs.shape)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def write_trace_files(datadir, real, mt, sf):
     """One text file per trace, in the layout load_input_data (:75-113) reads: data = t values,
     Green's functions = t rows x n component columns.  Returns the three file-name lists."""
@@ -237,6 +267,7 @@ if __name__ == "__main__":
     ref = load_reference()
     pipeline_case(ref, "ref_pipeline")
     samplers_case(ref, "ref_samplers")
+    multimedia_case(ref, "ref_multimedia")
     case(ref, "ref_mc_fullmt", 0, 5, 6, 160, 24, "full_mt")
     case(ref, "ref_mc_force", 1, 21, 3, 100, 16, "single_force")
     case(ref, "ref_mc_dc", 2, 3, 6, 512, 12, "DC")

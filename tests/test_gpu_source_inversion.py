@@ -275,3 +275,32 @@ def test_many_traces_take_the_lane_kernel_without_an_lds_limit(gpu):
     sim = si.score_samples(d, G, Ms, "PCC", True, False)[0]
     ref = mo.score_samples(G, d, Ms, "PCC", True, False)[0]
     assert np.allclose(sim, ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("typ", ["full_mt", "DC_single_force_couple"])
+def test_two_media_branch_on_gpu_vs_reference_golden(gpu, typ):
+    """invert_for_ratio_of_multiple_media_greens_func_switch (:715-727, :855-861) through the GPU scoring kernel
+    (the enlarged 6n-component problem takes the n > 9 moment kernel): samples, fraction rows, posterior and
+    likelihoods of the reference's own run, reproduced with its random stream."""
+    import random
+    from full_waveform_inversion_amd import source_inversion as si
+    g = np.load(os.path.join(GOLDEN, "ref_multimedia.npz"))
+    labels = [str(x) for x in g["labels"]]
+    seed = int(g["seed_" + typ])
+    np.random.seed(seed)
+    random.seed(seed)
+    MTs, MTp, MTp_abs = si.perform_monte_carlo_sampled_waveform_inversion(
+        g["d_" + typ], g["G2_" + typ], num_samples=g["MTs_" + typ].shape[1], M_amplitude=0.9, inversion_type=typ,
+        comparison_metric="VR", perform_normallised_waveform_inversion=False,
+        compare_all_waveforms_simultaneously=False, reference_stream=True,
+        invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_phase_labels=labels,
+        num_phase_types_for_media_ratios=3)
+    assert np.allclose(MTs, g["MTs_" + typ], rtol=1e-12, atol=1e-14)
+    assert np.allclose(MTp_abs, g["MTp_absolute_" + typ], rtol=1e-9, atol=0)
+    assert np.allclose(MTp, g["MTp_" + typ], rtol=1e-9, atol=0) and abs(MTp.sum() - 1.0) < 1e-12
+    # the default (seeded, non-reference) stream and the one-fraction variant run and normalise
+    MTs2, MTp2, _ = si.perform_monte_carlo_sampled_waveform_inversion(
+        g["d_" + typ], g["G2_" + typ], num_samples=500, inversion_type=typ, comparison_metric="PCC", seed=4,
+        invert_for_ratio_of_multiple_media_greens_func_switch=True)
+    assert MTs2.shape[0] == g["MTs_" + typ].shape[0] - 2 and abs(MTp2.sum() - 1.0) < 1e-12
+    assert (MTs2[-1] >= 0).all() and (MTs2[-1] <= 1).all()
