@@ -1,0 +1,49 @@
+"""The bench line's contract (driver: one JSON line with metric / value / roofline / cpu_baseline ...), checked on a
+small grid so that it runs in seconds: `bench.py --leg headline` and one extra leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_fields(gpu):
+    d = _run("--leg", "headline", "--grid", "64", "--nt", "40", "--steps", "2", "--warmup", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "Gpts/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["rccl_ranks"] is None
+    r = d["roofline"]
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] == "infinity-cache-resident"  # a 64^3 working set certainly is
+    # value = updates / wall time, consistent with ms_per_step
+    assert abs(d["value"] - 64 ** 3 * 40 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
+
+
+def test_an_extra_leg_alone_reports_its_roofline(gpu):
+    d = _run("--leg", "cfg2", "--leg-nt", "200")
+    leg = d["legs"]["cfg2"]
+    assert leg["kernel"] == "step2d_fused" and leg["Gpts_per_s"] > 50 and leg["us_per_time_step"] > 0
+    assert leg["algorithmic_bytes_per_launch"] == 4 * 16 * 1024 ** 2
+
+
+def test_more_ranks_than_launched_is_an_error_not_a_silent_single_gpu_run(gpu):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120, env={k: v for k, v in os.environ.items()
+                                                                  if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert p.returncode != 0 and b"torch.distributed.run" in p.stderr
