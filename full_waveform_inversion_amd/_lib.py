@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FWI_HIP_LIB") or os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -53,6 +53,7 @@ SIGNATURES = {
     "fwi_last_error": (C.c_char_p, [_P]),
     "fwi_set_model": (C.c_int, [_P, _P]),
     "fwi_forward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _I32, _P]),
+    "fwi_forward_spread": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I32, _P]),
     "fwi_adjoint": (C.c_int, [_P, _P, _I32, _P]),
     "fwi_misfit_l2": (C.c_int, [_P, _P, C.POINTER(_D)]),
     "fwi_gradient": (C.c_int, [_P, _I32, _P]),

@@ -103,6 +103,17 @@ struct fwi_ctx {
         void *pr_start = nullptr, *pr_ent = nullptr;
         size_t pcap = 0, pcap_start = 0;
     } src, rec;
+    // Off-grid points of the last forward (fwi_forward_spread): per point set the CSR over points, the owner of
+    // every node entry and its interpolation weight; time series cross the boundary per POINT and are scattered /
+    // gathered on the device.  npts = 0: node-based call.
+    struct SpreadSet {
+        int npts = 0;
+        void *pt_start = nullptr, *owner = nullptr, *weight = nullptr;
+        size_t cap = 0;
+    } src_sp, rec_sp;
+    void *pts_a = nullptr;   // (nt, npts) per-point series being uploaded / downloaded
+    void *pts_d = nullptr;   // (nt, nrec points) gathered synthetics of the last forward (fwi_misfit_l2)
+    size_t cap_pts_a = 0, cap_pts_d = 0;
     void *wav = nullptr;     // (nt, nsrc) source wavelets of the last forward (kept for recomputation)
     void *amp = nullptr;     // (nt, nrec) residual being back-propagated
     void *series = nullptr;  // (nt, n) sampled series of the running sweep
@@ -272,6 +283,32 @@ struct Impl {
         a.rec_scale = T(0);
         a.nrec = 0;
         return a;
+    }
+
+    // caller's per-point (or per-node) series -> the per-node device array `dst` (nt x nnodes)
+    static int upload_amplitudes(fwi_ctx *ctx, void *dst, const void *host, int nt, int nnodes,
+                                 const fwi_ctx::SpreadSet &sp) {
+        if (sp.npts == 0) return upload_series(ctx, dst, host, (size_t)nt * nnodes * sizeof(T));
+        int rc = ensure(ctx, &ctx->pts_a, &ctx->cap_pts_a, (size_t)nt * sp.npts * sizeof(T));
+        if (rc) return rc;
+        if ((rc = upload_series(ctx, ctx->pts_a, host, (size_t)nt * sp.npts * sizeof(T)))) return rc;
+        HIPCHK(ctx, launch_scatter_series<T>((const T *)ctx->pts_a, (T *)dst, (const int *)sp.owner, (const T *)sp.weight,
+                                             nt, sp.npts, nnodes, ctx->stream));
+        return FWI_OK;
+    }
+
+    // the per-node device series `src` (nt x nnodes) -> the caller, per node or gathered per point; `keep` (or
+    // nullptr) receives the device copy of what was handed out
+    static int download_samples(fwi_ctx *ctx, void *host, const void *src, int nt, int nnodes,
+                                const fwi_ctx::SpreadSet &sp, void **keep, size_t *keep_cap) {
+        if (sp.npts == 0) return download_series(ctx, host, src, host ? (size_t)nt * nnodes * sizeof(T) : 0);
+        void **buf = keep ? keep : &ctx->pts_a;
+        size_t *cap = keep ? keep_cap : &ctx->cap_pts_a;
+        int rc = ensure(ctx, buf, cap, (size_t)nt * sp.npts * sizeof(T));
+        if (rc) return rc;
+        HIPCHK(ctx, launch_gather_series<T>((const T *)src, (T *)*buf, (const int *)sp.pt_start, (const T *)sp.weight, nt,
+                                            sp.npts, nnodes, ctx->stream));
+        return download_series(ctx, host, *buf, host ? (size_t)nt * sp.npts * sizeof(T) : 0);
     }
 
     static PmlArgs<T> pml_args(fwi_ctx *ctx, const Sweep &sw, T *q_out) {
@@ -854,7 +891,7 @@ struct Impl {
         ctx->have_q = false;
         ctx->have_dev_residual = false;
         hipStream_t s = ctx->stream;
-        if (nsrc && (rc = upload_series(ctx, ctx->wav, wavelet, (size_t)nt * nsrc * sizeof(T)))) return rc;
+        if (nsrc && (rc = upload_amplitudes(ctx, ctx->wav, wavelet, nt, nsrc, ctx->src_sp))) return rc;
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
         Sweep sw;
         sw.f[0] = ctx->u[0];
@@ -921,8 +958,8 @@ struct Impl {
             ctx->fx[0] = spare[0];
             ctx->fx[1] = spare[1];
         }
-        if ((rc = download_series(ctx, seis_out, ctx->series,
-                                  (nrec && seis_out) ? (size_t)nt * nrec * sizeof(T) : 0)))
+        if ((rc = download_samples(ctx, (nrec && seis_out) ? seis_out : nullptr, ctx->series, nt, nrec, ctx->rec_sp,
+                                   &ctx->pts_d, &ctx->cap_pts_d)))
             return rc;
         ctx->have_forward = true;
         ctx->have_q = save != 0;
@@ -934,7 +971,7 @@ struct Impl {
         const int nt = ctx->nt, K = ctx->ckpt;
         hipStream_t s = ctx->stream;
         int rc;
-        if (ctx->nrec && residual && (rc = upload_series(ctx, ctx->amp, residual, (size_t)nt * ctx->nrec * sizeof(T))))
+        if (ctx->nrec && residual && (rc = upload_amplitudes(ctx, ctx->amp, residual, nt, ctx->nrec, ctx->rec_sp)))
             return rc;  // (residual == nullptr: the one fwi_misfit_l2 left in ctx->amp)
         ctx->have_dev_residual = false;  // consumed: ctx->series is about to be overwritten
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
@@ -1089,8 +1126,8 @@ struct Impl {
                                                (T)(1.0 / (double)rs), s));
         HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
         ctx->have_loop_time = true;
-        return download_series(ctx, adj_src_out, ctx->series,
-                               (adj_src_out && ctx->nsrc) ? (size_t)nt * ctx->nsrc * sizeof(T) : 0);
+        return download_samples(ctx, (adj_src_out && ctx->nsrc) ? adj_src_out : nullptr, ctx->series, nt, ctx->nsrc,
+                                ctx->src_sp, nullptr, nullptr);
     }
 
     static int gradient_vec(fwi_ctx *ctx, int32_t wrt, void *dev) {
@@ -1102,13 +1139,25 @@ struct Impl {
 
     // d_obs -> ctx->amp, then amp := series - amp and J = 1/2 sum amp^2, all on the device
     static int misfit_l2(fwi_ctx *ctx, const T *d_obs, double *J_out) {
-        const size_t n = (size_t)ctx->nt * ctx->nrec;
+        const fwi_ctx::SpreadSet &sp = ctx->rec_sp;
+        const size_t n = (size_t)ctx->nt * (sp.npts ? sp.npts : ctx->nrec);
         double ss = 0.0;
-        if (n) {
-            int rc = upload_series(ctx, ctx->amp, d_obs, n * sizeof(T));
-            if (rc) return rc;
+        if (n && ctx->nrec) {
+            // off-grid receivers: the residual lives per POINT (against the gathered synthetics kept by the forward)
+            // and is then scattered onto the nodes, where the adjoint sweep injects it
+            void *resid = ctx->amp;
+            int rc;
+            if (sp.npts) {
+                if ((rc = ensure(ctx, &ctx->pts_a, &ctx->cap_pts_a, n * sizeof(T)))) return rc;
+                resid = ctx->pts_a;
+            }
+            if ((rc = upload_series(ctx, resid, d_obs, n * sizeof(T)))) return rc;
             HIPCHK(ctx, hipMemsetAsync(ctx->red, 0, sizeof(double), ctx->stream));
-            HIPCHK(ctx, launch_residual_l2<T>((const T *)ctx->series, (T *)ctx->amp, (int64_t)n, ctx->red, ctx->stream));
+            HIPCHK(ctx, launch_residual_l2<T>((const T *)(sp.npts ? ctx->pts_d : ctx->series), (T *)resid, (int64_t)n,
+                                              ctx->red, ctx->stream));
+            if (sp.npts)
+                HIPCHK(ctx, launch_scatter_series<T>((const T *)resid, (T *)ctx->amp, (const int *)sp.owner,
+                                                     (const T *)sp.weight, ctx->nt, sp.npts, ctx->nrec, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(&ss, ctx->red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
@@ -1414,6 +1463,11 @@ void fwi_destroy(fwi_ctx *ctx) {
     for (int d = 0; d < 3; ++d)
         for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d]})
             if (q) (void)hipFree(q);
+    for (fwi_ctx::SpreadSet *sp : {&ctx->src_sp, &ctx->rec_sp})
+        for (void *q : {sp->pt_start, sp->owner, sp->weight})
+            if (q) (void)hipFree(q);
+    for (void *q : {ctx->pts_a, ctx->pts_d})
+        if (q) (void)hipFree(q);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1441,11 +1495,73 @@ int fwi_forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx, 
     if ((nsrc && (!src_idx || !wavelet)) || (nrec && (!rec_idx || !seis_out)))
         return ctx->fail(FWI_EINVAL, "fwi_forward: null buffer");
     (void)hipSetDevice(ctx->cfg.device);
+    ctx->src_sp.npts = ctx->rec_sp.npts = 0;  // node-based call
     return DISPATCH(ctx,
                     Impl<float>::forward(ctx, nt, nsrc, src_idx, (const float *)wavelet, nrec, rec_idx,
                                          save, (float *)seis_out),
                     Impl<double>::forward(ctx, nt, nsrc, src_idx, (const double *)wavelet, nrec,
                                           rec_idx, save, (double *)seis_out));
+}
+
+// nodes of point p = entries pt_start[p] .. pt_start[p + 1] of the node list (at most 8); weight per entry
+static int set_spread(fwi_ctx *ctx, fwi_ctx::SpreadSet &sp, int32_t npts, int32_t nnodes, const int32_t *pt_start,
+                      const void *weight, const char *what) {
+    sp.npts = 0;
+    if (npts < 0 || (npts > 0 && (!pt_start || !weight)))
+        return ctx->fail(FWI_EINVAL, "fwi_forward_spread: bad %s point set", what);
+    if (npts == 0) {
+        if (nnodes != 0) return ctx->fail(FWI_EINVAL, "fwi_forward_spread: %s nodes without points", what);
+        return FWI_OK;
+    }
+    std::vector<int> owner((size_t)nnodes);
+    if (pt_start[0] != 0 || pt_start[npts] != nnodes)
+        return ctx->fail(FWI_EINVAL, "fwi_forward_spread: %s pt_start must run from 0 to the node count", what);
+    for (int p = 0; p < npts; ++p) {
+        const int a = pt_start[p], b = pt_start[p + 1];
+        if (b < a || b - a > 8)
+            return ctx->fail(FWI_EINVAL, "fwi_forward_spread: %s point %d has %d nodes (0..8 allowed)", what, p, b - a);
+        for (int m = a; m < b; ++m) owner[m] = p;
+    }
+    const size_t need = (size_t)std::max(nnodes, npts + 1) * 8 + 16;
+    if (sp.cap < need) {
+        for (void **q : {&sp.pt_start, &sp.owner, &sp.weight}) {
+            if (*q) HIPCHK(ctx, hipFree(*q));
+            *q = nullptr;
+            HIPCHK(ctx, hipMalloc(q, need));
+        }
+        sp.cap = need;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(sp.pt_start, pt_start, (size_t)(npts + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(sp.owner, owner.data(), (size_t)nnodes * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(sp.weight, weight, (size_t)nnodes * ctx->esize, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `owner` goes out of scope
+    sp.npts = npts;
+    return FWI_OK;
+}
+
+int fwi_forward_spread(fwi_ctx *ctx, int32_t nt, int32_t nsrc_pts, int32_t nsrc_nodes, const int32_t *src_idx,
+                       const int32_t *src_pt_start, const void *src_weight, const void *wavelet, int32_t nrec_pts,
+                       int32_t nrec_nodes, const int32_t *rec_idx, const int32_t *rec_pt_start, const void *rec_weight,
+                       int32_t save, void *seis_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->have_model) return ctx->fail(FWI_ESTATE, "fwi_forward_spread: call fwi_set_model first");
+    if (nt < 1 || nt > ctx->cfg.nt_max)
+        return ctx->fail(FWI_EINVAL, "fwi_forward_spread: nt=%d outside [1, nt_max=%d]", nt, ctx->cfg.nt_max);
+    if (nsrc_nodes < 0 || nrec_nodes < 0) return ctx->fail(FWI_EINVAL, "fwi_forward_spread: negative node count");
+    if ((nsrc_nodes && (!src_idx || !wavelet)) || (nrec_nodes && (!rec_idx || !seis_out)))
+        return ctx->fail(FWI_EINVAL, "fwi_forward_spread: null buffer");
+    (void)hipSetDevice(ctx->cfg.device);
+    int rc = set_spread(ctx, ctx->src_sp, nsrc_pts, nsrc_nodes, src_pt_start, src_weight, "source");
+    if (!rc) rc = set_spread(ctx, ctx->rec_sp, nrec_pts, nrec_nodes, rec_pt_start, rec_weight, "receiver");
+    if (rc) {
+        ctx->src_sp.npts = ctx->rec_sp.npts = 0;
+        return rc;
+    }
+    return DISPATCH(ctx,
+                    Impl<float>::forward(ctx, nt, nsrc_nodes, src_idx, (const float *)wavelet, nrec_nodes, rec_idx, save,
+                                         (float *)seis_out),
+                    Impl<double>::forward(ctx, nt, nsrc_nodes, src_idx, (const double *)wavelet, nrec_nodes, rec_idx,
+                                          save, (double *)seis_out));
 }
 
 int fwi_adjoint(fwi_ctx *ctx, const void *residual, int32_t image, void *adj_src_out) {

@@ -119,6 +119,14 @@ hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);
 
+// off-grid points: per-point (nt, npts) <-> per-node (nt, nnodes) time series; a point's nodes are entries
+// pt_start[p] .. pt_start[p + 1] (at most 8), owner[m] is the point of entry m, w[m] its interpolation weight
+template <typename T>
+hipError_t launch_scatter_series(const T *pt, T *node, const int *owner, const T *w, int nt, int npts, int nnodes,
+                                 hipStream_t s);
+template <typename T>
+hipError_t launch_gather_series(const T *node, T *pt, const int *pt_start, const T *w, int nt, int npts, int nnodes,
+                                hipStream_t s);
 // obs_inout := syn - obs_inout; *out += sum of its squares (out zeroed by the caller)
 template <typename T>
 hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out, hipStream_t s);

@@ -1061,6 +1061,57 @@ hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out
     return hipGetLastError();
 }
 
+// Off-grid points (multilinear interpolation): per-point time series <-> per-node time series on the device.
+//   scatter  node[n, m] = w[m] * point[n, owner[m]]                      (injection amplitudes)
+//   gather   point[n, p] = sum_{m in nodes(p)} w[m] * node[n, m]         (sampling; the transpose)
+// gather: a point has at most 2^D <= 8 nodes, so 8 lanes own one (time sample, point) pair and reduce with
+// __shfl_down within their group of 8 -- the "wavefront reduction for the receiver gather" of north_star.
+template <typename T>
+__global__ void scatter_series_kernel(const T *pt, T *node, const int *owner, const T *w, int nt, int npts, int nnodes) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nt * nnodes) return;
+    const int n = (int)(i / nnodes), m = (int)(i - (int64_t)n * nnodes);
+    node[i] = w[m] * pt[(int64_t)n * npts + owner[m]];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_series_kernel(const T *node, T *pt, const int *pt_start, const T *w, int nt,
+                                                            int npts, int nnodes) {
+    const int64_t pair = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3;  // (n, p), 8 lanes each
+    const int sub = threadIdx.x & 7;
+    T v = T(0);
+    const bool live = pair < (int64_t)nt * npts;
+    int n = 0, p = 0;
+    if (live) {
+        n = (int)(pair / npts);
+        p = (int)(pair - (int64_t)n * npts);
+        const int m = pt_start[p] + sub;
+        if (m < pt_start[p + 1]) v = w[m] * node[(int64_t)n * nnodes + m];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) v += __shfl_down(v, off, 8);
+    if (live && sub == 0) pt[pair] = v;
+}
+
+template <typename T>
+hipError_t launch_scatter_series(const T *pt, T *node, const int *owner, const T *w, int nt, int npts, int nnodes,
+                                 hipStream_t s) {
+    const int64_t tot = (int64_t)nt * nnodes;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_series_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, pt, node, owner, w,
+                       nt, npts, nnodes);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_gather_series(const T *node, T *pt, const int *pt_start, const T *w, int nt, int npts, int nnodes,
+                                hipStream_t s) {
+    const int64_t tot = (int64_t)nt * npts * 8;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_series_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, node, pt, pt_start,
+                       w, nt, npts, nnodes);
+    return hipGetLastError();
+}
+
 // Model-sized vector algebra for the optimiser (device-resident L-BFGS state).
 template <typename T>
 __global__ void axpby_kernel(T *y, double a, const T *x, double b, int64_t n) {
@@ -1120,6 +1171,8 @@ hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
     template hipError_t launch_repack<T>(const GridDesc &, T *, const T *, int, hipStream_t);       \
     template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
     template hipError_t launch_residual_l2<T>(const T *, T *, int64_t, double *, hipStream_t);       \
+    template hipError_t launch_scatter_series<T>(const T *, T *, const int *, const T *, int, int, int, hipStream_t); \
+    template hipError_t launch_gather_series<T>(const T *, T *, const int *, const T *, int, int, int, hipStream_t);  \
     template hipError_t launch_build_model<T>(const GridDesc &, const T *, T *, double, int *, hipStream_t); \
     template hipError_t launch_axpby<T>(T *, double, const T *, double, int64_t, hipStream_t);         \
     template hipError_t launch_clip<T>(const GridDesc &, T *, double, double, hipStream_t);           \

@@ -166,6 +166,35 @@ class Engine:
         self._nt, self._nsrc, self._nrec = nt, len(src_idx), len(rec_idx)
         return seis
 
+    def forward_at(self, model, src, rec, save=True):
+        """``forward`` with sources / receivers at fractional grid coordinates (cells; multilinear interpolation):
+        ``src = (src_xyz (nsrc, ndim) | points.Spread, wavelet (nt[, nsrc]))``, ``rec = rec_xyz | Spread``.
+        The per-point series are spread onto / gathered from the grid nodes ON THE DEVICE (``fwi_forward_spread``);
+        the following ``adjoint`` / ``misfit_l2`` then work per point as well."""
+        from .points import Spread
+        if model is not None:
+            self.set_model(model)
+        if self._ctx is None:
+            raise _lib.FwiError(3, "forward_at: no model set")
+        S, wavelet = src
+        S = S if isinstance(S, Spread) else Spread(S, self.shape)
+        R = rec if isinstance(rec, Spread) else Spread(rec, self.shape)
+        wavelet = np.asarray(wavelet)
+        if wavelet.ndim == 1:
+            wavelet = wavelet[:, None]
+        wavelet = self._host(wavelet)
+        nt = wavelet.shape[0]
+        if wavelet.shape[1] != S.n:
+            raise ValueError("wavelet must be (nt, nsrc points)")
+        sw, rw = self._host(S.weights), self._host(R.weights)
+        seis = np.zeros((nt, R.n), self.dtype)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._chk(self._lib.fwi_forward_spread(
+            self._ctx, nt, S.n, len(S.idx), vp(S.idx), vp(S.pt_start), vp(sw), vp(wavelet), R.n, len(R.idx),
+            vp(R.idx), vp(R.pt_start), vp(rw), int(bool(save)), vp(seis)))
+        self._nt, self._nsrc, self._nrec = nt, S.n, R.n
+        return seis
+
     def adjoint(self, residual, image=True):
         """Back-propagate ``residual (nt, nrec)``; returns ``F^T residual`` as ``(nt, nsrc)``.
         ``residual=None``: the residual :meth:`misfit_l2` formed on the device."""

@@ -48,9 +48,11 @@ class Spread:
             wts.append(w[ok])
             own.append(np.nonzero(ok)[0])
         self.n = coords.shape[0]
-        self.idx = np.ascontiguousarray(np.concatenate(idx), dtype=np.int32)   # (m, D) nodes
-        self.weights = np.concatenate(wts)                                      # (m,)
-        self.owner = np.concatenate(own)                                        # (m,) point of each node entry
+        order = np.argsort(np.concatenate(own), kind="stable")  # entries grouped by point (the device gather's CSR)
+        self.idx = np.ascontiguousarray(np.concatenate(idx)[order], dtype=np.int32)   # (m, D) nodes
+        self.weights = np.concatenate(wts)[order]                                      # (m,)
+        self.owner = np.concatenate(own)[order]                                        # (m,) point of each node entry
+        self.pt_start = np.concatenate(([0], np.cumsum(np.bincount(self.owner, minlength=self.n)))).astype(np.int32)
 
     def scatter(self, a):
         """Per-point time series ``(nt, n)`` (or ``(nt,)`` for one point) -> per-node series ``(nt, m)``."""

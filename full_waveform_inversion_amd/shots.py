@@ -24,21 +24,31 @@ class Shot:
     # the data are gathered back to the points; see Shot.at_coordinates
     src_spread: object = None
     rec_spread: object = None
+    point_wavelet: np.ndarray | None = None  # (nt[, nsrc points]): the wavelets before spreading
 
     @classmethod
     def at_coordinates(cls, src_xyz, wavelet, rec_xyz, shape, d_obs=None):
         """A shot whose sources / receivers sit at fractional grid coordinates (multilinear interpolation)."""
         from .points import Spread
         S, R = Spread(src_xyz, shape), Spread(rec_xyz, shape)
-        return cls(S.idx, S.scatter(wavelet), R.idx, d_obs, S, R)
+        return cls(S.idx, S.scatter(wavelet), R.idx, d_obs, S, R, np.asarray(wavelet))
+
+    def _on_device(self, engine):
+        """off-grid points and an engine that spreads / gathers them on the device (fwi_forward_spread)"""
+        return self.src_spread is not None and self.rec_spread is not None and hasattr(engine, "forward_at")
 
     def forward(self, engine, save):
         """Seismograms at this shot's receivers, ``(nt, nrec)``."""
+        if self._on_device(engine):
+            return engine.forward_at(None, (self.src_spread, self.point_wavelet), self.rec_spread, save=save)
         d = engine.forward(None, (self.src_idx, self.wavelet), self.rec_idx, save=save)
         return self.rec_spread.gather(d) if self.rec_spread is not None else d
 
     def adjoint(self, engine, residual):
         """Back-propagate a residual given at this shot's receivers (imaging into the engine's accumulator)."""
+        if self._on_device(engine):
+            engine.adjoint(None if residual is None else np.ascontiguousarray(residual))
+            return
         r = self.rec_spread.scatter(residual) if self.rec_spread is not None else residual
         engine.adjoint(np.ascontiguousarray(r))
 
@@ -217,8 +227,8 @@ def _sweep_shots(engine, shots, ex, objective):
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
         d = s.forward(e, save=True)
-        if objective is l2 and s.rec_spread is None and hasattr(e, "misfit_l2"):
-            # least squares on node receivers: residual and misfit are formed on the device
+        if objective is l2 and hasattr(e, "misfit_l2") and (s.rec_spread is None or s._on_device(e)):
+            # least squares: residual and misfit are formed on the device (per node, or per off-grid point)
             j = e.misfit_l2(s.d_obs)
             e.adjoint(None)
             return j

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 10
+#define FWI_ABI_VERSION 11
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -124,6 +124,19 @@ int fwi_set_model(fwi_ctx *ctx, const void *c_host);
 int fwi_forward(fwi_ctx *ctx, int32_t nt, int32_t nsrc, const int32_t *src_idx,
                 const void *wavelet, int32_t nrec, const int32_t *rec_idx, int32_t save,
                 void *seis_out);
+
+/* forward() with OFF-GRID sources / receivers (multilinear interpolation onto the surrounding nodes).  The node
+ * lists (src_idx / rec_idx, as for fwi_forward) hold every point's nodes contiguously: point p owns entries
+ * pt_start[p] .. pt_start[p + 1] (at most 8 = 2^3; pt_start has npts + 1 entries), each with its interpolation
+ * weight (context dtype).  Time series cross the boundary PER POINT -- wavelet (nt, nsrc_pts), seis_out
+ * (nt, nrec_pts) -- and are scattered onto / gathered from the nodes on the device, the gather by a wave-level
+ * __shfl_down reduction over each point's 8 lanes.  The following fwi_adjoint / fwi_misfit_l2 take and return
+ * per-point series too.  npts = 0 with nodes = 0: no points of that kind.
+ * [north_star "__shfl-based wavefront reductions for the receiver gather"; SURVEY s.8(a-1) row receiver sampling] */
+int fwi_forward_spread(fwi_ctx *ctx, int32_t nt, int32_t nsrc_pts, int32_t nsrc_nodes, const int32_t *src_idx,
+                       const int32_t *src_pt_start, const void *src_weight, const void *wavelet, int32_t nrec_pts,
+                       int32_t nrec_nodes, const int32_t *rec_idx, const int32_t *rec_pt_start, const void *rec_weight,
+                       int32_t save, void *seis_out);
 
 /* adjoint(residual): reverse-time propagation of residual (nt, nrec) injected
  * at the receivers of the last forward.  image != 0 accumulates the zero-lag

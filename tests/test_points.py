@@ -98,3 +98,73 @@ def test_shot_at_coordinates_gradient_matches_finite_differences():
     Jm, _ = sh.misfit_and_gradient(e, c0 - eps * dc, shots)
     fd, an = (Jp - Jm) / (2 * eps), float(np.sum(g * dc))
     assert abs(fd - an) <= 1e-6 * abs(an), (fd, an)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype,tol", [((30, 26, 34), "float64", 1e-12), ((30, 26, 34), "float32", 2e-6),
+                                             ((40, 44), "float64", 1e-12), ((40, 44), "float32", 2e-6)])
+def test_device_spread_and_gather_equal_the_host_ones(gpu, shape, dtype, tol):
+    """fwi_forward_spread: the per-point wavelets are scattered onto the nodes and the node samples gathered per
+    point ON THE DEVICE (wave-level __shfl_down over each point's <= 8 nodes); the same for the residual and the
+    adjoint source series -- equal to points.Spread's host scatter / gather around the node-based calls, points
+    on nodes, on the last plane and duplicates included; misfit and gradient through the shot loop likewise."""
+    from full_waveform_inversion_amd import Engine, shots as sh
+    from oracle import fwi_oracle as fo
+    rng = np.random.default_rng(8)
+    nd = len(shape)
+    h, order, nt = 10.0, 8, 70
+    c = 2000.0 + 300.0 * rng.random(shape)
+    dt = 0.6 * fo.cfl_dt(c.max(), h, nd, order)
+    lim = np.array(shape) - 1.0
+    src = rng.random((3, nd)) * lim
+    src[1] = np.floor(src[1])                       # exactly on a node
+    rec = rng.random((9, nd)) * lim
+    rec[0] = lim                                    # the far corner
+    rec[1, 0] = lim[0]                              # on the last plane
+    rec[2] = rec[3]                                 # two receivers at one place
+    S, R = Spread(src, shape), Spread(rec, shape)
+    w = rng.standard_normal((nt, 3)).astype(dtype)
+    r = rng.standard_normal((nt, 9)).astype(dtype)
+    with Engine(shape, h, dt, nt, order=order, npml=4, sigma_max=300.0, dtype=dtype) as e:
+        d_host = R.gather(e.forward(c, (S.idx, S.scatter(w)), R.idx, save=True))
+        a_host = S.gather(e.adjoint(R.scatter(r)))
+        g_host = e.gradient()
+        e.reset_gradient()
+        d_dev = e.forward_at(None, (src, w), rec, save=True)
+        a_dev = e.adjoint(r)
+        g_dev = e.gradient()
+        scale = lambda x: np.linalg.norm(x)  # noqa: E731
+        assert d_dev.shape == (nt, 9) and a_dev.shape == (nt, 3)
+        assert scale(d_dev - d_host) <= tol * scale(d_host)
+        assert scale(a_dev - a_host) <= tol * scale(a_host)
+        assert scale(g_dev - g_host) <= tol * scale(g_host)
+        assert np.array_equal(d_dev[:, 2], d_dev[:, 3])
+        # device misfit on the gathered traces, residual scattered on the device too
+        e.reset_gradient()
+        d_obs = (d_dev * 0.9).astype(dtype)
+        e.forward_at(None, (src, w), rec, save=True)
+        J = e.misfit_l2(d_obs)
+        e.adjoint(None)
+        g2 = e.gradient()
+        e.reset_gradient()
+        e.forward_at(None, (src, w), rec, save=True)
+        e.adjoint((d_dev - d_obs).astype(dtype))
+        assert abs(J - 0.5 * float(np.sum((d_dev.astype(np.float64) - d_obs) ** 2))) <= 1e-6 * J
+        assert scale(g2 - e.gradient()) <= max(tol, 1e-7) * scale(g2)
+        # a node-based call afterwards is a node-based call again
+        assert e.forward(None, (S.idx, S.scatter(w)), R.idx, save=False).shape == (nt, len(R.idx))
+        # the shot loop takes the device path for such shots
+        shot = sh.Shot.at_coordinates(src, w, rec, shape, d_obs=d_obs)
+        J3, g3 = sh.misfit_and_gradient(e, c.astype(dtype), [shot])
+        assert abs(J3 - J) <= 1e-6 * J and scale(g3 - e.gradient()) >= 0  # (runs; the value is pinned just below)
+        e.reset_gradient()
+        e.forward_at(None, (src, w), rec, save=True)
+        e.misfit_l2(d_obs)
+        e.adjoint(None)
+        assert scale(g3 - e.gradient("velocity")) <= max(tol, 1e-7) * scale(g3)
+        import ctypes as C
+        with pytest.raises(Exception):  # a point with more than 8 nodes is refused
+            bad = np.array([0, 9], np.int32)
+            e._chk(e._lib.fwi_forward_spread(e._ctx, nt, 1, 9, S.idx.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p),
+                                             np.ones(9, dtype).ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                             0, 0, None, None, None, 0, None))
