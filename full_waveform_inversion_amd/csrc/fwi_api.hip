@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,12 +92,12 @@ struct fwi_ctx {
         int n = 0;
         void *pidx = nullptr, *cidx = nullptr, *cu = nullptr, *cq = nullptr;
         void *s_start = nullptr, *s_pidx = nullptr, *s_cidx = nullptr, *s_cu = nullptr, *s_cq = nullptr,
-             *s_col = nullptr;
+             *s_col = nullptr, *s_run = nullptr;
         size_t cap = 0, cap_start = 0;
         // tables for the 2-D fused kernel: injection entries per tile (extended region) and
         // sampling entries per tile (interior)
         void *fi_start = nullptr, *fi_lz = nullptr, *fi_lx = nullptr, *fi_col = nullptr, *fi_int = nullptr,
-             *fi_cidx = nullptr, *fi_cu = nullptr, *fi_cq = nullptr;
+             *fi_cidx = nullptr, *fi_cu = nullptr, *fi_cq = nullptr, *fi_run = nullptr;
         void *fr_start = nullptr, *fr_lz = nullptr, *fr_lx = nullptr, *fr_col = nullptr;
         size_t fcap = 0, fcap_start = 0;
         // entries of the 3-D two-step kernel, CSR over its workgroups
@@ -278,6 +279,7 @@ struct Impl {
         a.inj_pidx = a.inj_cidx = nullptr;
         a.inj_cu = a.inj_cq = a.inj_amp = nullptr;
         a.inj_col = nullptr;
+        a.inj_run = nullptr;
         a.rec_pidx = nullptr;
         a.rec_out = nullptr;
         a.rec_scale = T(0);
@@ -431,7 +433,7 @@ struct Impl {
         const size_t need = (size_t)n * 8 + 16;
         if (ps.cap < need) {
             for (void **q : {&ps.pidx, &ps.cidx, &ps.cu, &ps.cq, &ps.s_pidx, &ps.s_cidx, &ps.s_cu, &ps.s_cq,
-                             &ps.s_col}) {
+                             &ps.s_col, &ps.s_run}) {
                 if (*q) HIPCHK(ctx, hipFree(*q));
                 *q = nullptr;
                 HIPCHK(ctx, hipMalloc(q, need));
@@ -469,11 +471,22 @@ struct Impl {
                 ++start[tile[i] + 1];
             }
             for (int k = 0; k < ntile; ++k) start[k + 1] += start[k];
-            std::vector<int> fill(start.begin(), start.end() - 1);
+            // within a tile by node, then by entry: the entries of one node are consecutive (the kernels add such a
+            // run from one thread in this order, inject_runs)
+            std::vector<int> ord(n);
+            for (int i = 0; i < n; ++i) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+                return tile[x] != tile[y] ? tile[x] < tile[y] : p[x] < p[y];
+            });
             col.resize(n); sp.resize(n); sc.resize(n); scu.resize(n); scq.resize(n);
-            for (int i = 0; i < n; ++i) {
-                const int k = fill[tile[i]]++;
+            std::vector<int> run(n, 0);
+            for (int k = 0; k < n; ++k) {
+                const int i = ord[k];
                 col[k] = i; sp[k] = p[i]; sc[k] = c[i]; scu[k] = cu[i]; scq[k] = cq[i];
+            }
+            for (int k = n - 1, len = 0; k >= 0; --k) {  // run length at the first entry of each node's run
+                len = (k + 1 < n && sp[k + 1] == sp[k] && tile[ord[k + 1]] == tile[ord[k]]) ? len + 1 : 1;
+                run[k] = (k == 0 || sp[k - 1] != sp[k] || tile[ord[k - 1]] != tile[ord[k]]) ? len : 0;
             }
             const size_t sb = start.size() * sizeof(int);
             if (ps.cap_start < sb) {
@@ -488,6 +501,7 @@ struct Impl {
             HIPCHK(ctx, up(ps.s_cu, scu.data(), (size_t)n * sizeof(T)));
             HIPCHK(ctx, up(ps.s_cq, scq.data(), (size_t)n * sizeof(T)));
             HIPCHK(ctx, up(ps.s_col, col.data(), (size_t)n * sizeof(int)));
+            HIPCHK(ctx, up(ps.s_run, run.data(), (size_t)n * sizeof(int)));
         }
         std::vector<int> fst, flz, flx, fcol, rst, rlz, rlx, rcol;
         std::vector<unsigned char> fint;
@@ -513,6 +527,10 @@ struct Impl {
                     }
                 }
             }
+            std::stable_sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) {
+                if (x.tile != y.tile) return x.tile < y.tile;
+                return x.lz != y.lz ? x.lz < y.lz : x.lx < y.lx;  // a node's entries consecutive, in entry order
+            });
             auto build = [&](bool interior_only, std::vector<int> &st, std::vector<int> &lz, std::vector<int> &lx,
                              std::vector<int> &col, std::vector<int> *order) {
                 st.assign(ntile + 1, 0);
@@ -543,7 +561,7 @@ struct Impl {
             const size_t fneed = ne * 8 + 16, sneed = (size_t)(ntile + 1) * sizeof(int);
             if (ps.fcap < fneed) {
                 for (void **q : {&ps.fi_lz, &ps.fi_lx, &ps.fi_col, &ps.fi_int, &ps.fi_cidx, &ps.fi_cu, &ps.fi_cq,
-                                 &ps.fr_lz, &ps.fr_lx, &ps.fr_col}) {
+                                 &ps.fi_run, &ps.fr_lz, &ps.fr_lx, &ps.fr_col}) {
                     if (*q) HIPCHK(ctx, hipFree(*q));
                     *q = nullptr;
                     HIPCHK(ctx, hipMalloc(q, fneed));
@@ -567,6 +585,19 @@ struct Impl {
             HIPCHK(ctx, up(ps.fi_cidx, fcidx.data(), ne * 8));
             HIPCHK(ctx, up(ps.fi_cu, fcu.data(), ne * sizeof(T)));
             HIPCHK(ctx, up(ps.fi_cq, fcq.data(), ne * sizeof(T)));
+            {
+                std::vector<int> frun(ne, 0);  // run length at the first entry of each (tile, node) run
+                for (int k = (int)ne - 1, len = 0; k >= 0; --k) {
+                    auto same = [&](int x, int y) {
+                        const Ent &ex = ents[order[x]], &ey = ents[order[y]];
+                        return ex.tile == ey.tile && ex.lz == ey.lz && ex.lx == ey.lx;
+                    };
+                    len = (k + 1 < (int)ne && same(k, k + 1)) ? len + 1 : 1;
+                    frun[k] = (k == 0 || !same(k - 1, k)) ? len : 0;
+                }
+                HIPCHK(ctx, up(ps.fi_run, frun.data(), ne * sizeof(int)));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // frun goes out of scope
+            }
             HIPCHK(ctx, up(ps.fr_lz, rlz.data(), rlz.size() * sizeof(int)));
             HIPCHK(ctx, up(ps.fr_lx, rlx.data(), rlx.size() * sizeof(int)));
             HIPCHK(ctx, up(ps.fr_col, rcol.data(), rcol.size() * sizeof(int)));
@@ -713,6 +744,7 @@ struct Impl {
                     a.inj_lx = (const int *)inj.fi_lx;
                     a.inj_col = (const int *)inj.fi_col;
                     a.inj_interior = (const unsigned char *)inj.fi_int;
+                    a.inj_run = (const int *)inj.fi_run;
                     a.inj_cidx = (const int64_t *)inj.fi_cidx;
                     a.inj_cu = (const float *)inj.fi_cu;
                     a.inj_cq = (const float *)inj.fi_cq;
@@ -788,6 +820,7 @@ struct Impl {
                 a.inj_cu = (const T *)inj.s_cu;
                 a.inj_cq = (const T *)inj.s_cq;
                 a.inj_col = (const int *)inj.s_col;
+                a.inj_run = (const int *)inj.s_run;
                 a.inj_amp = amp + (size_t)n * inj.n;
             }
             if (out && sw.prev_n >= 0 && out->n > 0) {
@@ -1452,7 +1485,7 @@ void fwi_destroy(fwi_ctx *ctx) {
                     ctx->fwd[1], ctx->fx[0], ctx->fx[1], ctx->fwx[0], ctx->fwx[1], ctx->logical, ctx->vf, ctx->fwv};
     for (fwi_ctx::PointSet *ps : {&ctx->src, &ctx->rec})
         for (void *p : {ps->pidx, ps->cidx, ps->cu, ps->cq, ps->s_start, ps->s_pidx, ps->s_cidx, ps->s_cu,
-                        ps->s_cq, ps->s_col, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,
+                        ps->s_cq, ps->s_col, ps->s_run, ps->fi_run, ps->fi_start, ps->fi_lz, ps->fi_lx, ps->fi_col, ps->fi_int,
                         ps->fi_cidx, ps->fi_cu, ps->fi_cq, ps->fr_start, ps->fr_lz, ps->fr_lx, ps->fr_col, ps->pr_start,
                         ps->pr_ent})
             if (p) (void)hipFree(p);

@@ -229,12 +229,21 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
         __syncthreads();  // u^{n+1} complete in prv; (also drains this wave's q stores)
         // ---- injection into the new field (entries of this tile's extended region) -------------------
         if (s1 > s0) {
+            // the host sorts a tile's entries by node: the thread of a run's first entry adds the whole run in entry
+            // order -- one add per node, so duplicate nodes sum reproducibly
             for (int i = s0 + tid; i < s1; i += FNT) {
-                const float amp = a.inj_amp[(int64_t)n * a.ninj + a.inj_col[i]];
+                const int run = a.inj_run[i];
                 const int lz = a.inj_lz[i], lx = a.inj_lx[i];
-                atomicAdd(&prv[lz][lx >> 2].v[lx & 3], a.inj_cu[i] * amp);
-                if (SAVE_Q && qstep && a.inj_interior[i])
-                    atomicAdd(qslot + a.inj_cidx[i], a.inj_cq[i] * amp);
+                const float amp0 = a.inj_amp[(int64_t)n * a.ninj + a.inj_col[i]];
+                float su = a.inj_cu[i] * amp0, sq = a.inj_cq[i] * amp0;
+                if (run == 0) continue;
+                for (int j = i + 1; j < i + run; ++j) {
+                    const float amp = a.inj_amp[(int64_t)n * a.ninj + a.inj_col[j]];
+                    su += a.inj_cu[j] * amp;
+                    sq += a.inj_cq[j] * amp;
+                }
+                atomicAdd(&prv[lz][lx >> 2].v[lx & 3], su);  // (one ds_add per node: no read-back latency)
+                if (SAVE_Q && qstep && a.inj_interior[i]) atomicAdd(qslot + a.inj_cidx[i], sq);  // (no round trip)
             }
             __syncthreads();
         }

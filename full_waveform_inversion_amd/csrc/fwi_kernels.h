@@ -60,6 +60,8 @@ struct StepArgs {
     const int64_t *inj_pidx, *inj_cidx;  // padded / compact flat index per entry
     const T *inj_cu, *inj_cq;            // coefficient of the amplitude in u / in q
     const int *inj_col;                  // column of the entry in the amplitude row
+    const int *inj_run;                  // entries of this entry's node that follow from here (>= 1) if it is the first
+                                         // of its node's run, 0 otherwise (entries of a node are consecutive)
     const T *inj_amp;                    // amplitude row of this time step
     // Sampling of u_cur (= the previous step's result) by extra workgroups.
     const int64_t *rec_pidx;
@@ -168,6 +170,7 @@ struct Fused2dArgs {
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
     const int *inj_start, *inj_lz, *inj_lx, *inj_col;
     const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)
+    const int *inj_run;                 // run length at the first entry of a node's run, 0 at the others
     const int64_t *inj_cidx;
     const float *inj_cu, *inj_cq;
     const float *inj_amp;               // (nt, ninj) amplitudes, row n used by step n

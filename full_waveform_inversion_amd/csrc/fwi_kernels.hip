@@ -43,6 +43,34 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     return g;
 }
 
+// Source / residual injection into the points a workgroup has just written.  The host sorts a tile's entries by
+// node, so the entries of one node are consecutive: the thread of a run's FIRST entry adds the whole run, in entry
+// order, and issues ONE add per node -- duplicate nodes (two sources on one node) sum in a fixed order:
+// bit-reproducible.  A node belongs to exactly one tile, so no other workgroup touches it; the caller's barrier has
+// drained this workgroup's own stores of u'.
+template <typename T, bool INC, bool Q>
+__device__ __forceinline__ void inject_runs(const StepArgs<T> &a, int s0, int s1, int tid, int nth) {
+    for (int i = s0 + tid; i < s1; i += nth) {
+        // entry i's operands all at once (one level of loads, then the amplitude): the common run of 1 costs what
+        // the plain per-entry form did
+        const int run = a.inj_run[i];  // host-made: length of the node's run at its first entry, 0 at the others
+        const int64_t p = a.inj_pidx[i];
+        const T amp0 = a.inj_amp[a.inj_col[i]];
+        T su = a.inj_cu[i] * amp0, sq = Q ? a.inj_cq[i] * amp0 : T(0);
+        if (run == 0) continue;  // a later entry of its node's run: the first one's thread adds it
+        for (int j = i + 1; j < i + run; ++j) {
+            const T amp = a.inj_amp[a.inj_col[j]];
+            su += a.inj_cu[j] * amp;
+            if (Q) sq += a.inj_cq[j] * amp;
+        }
+        // ONE add per node and field: atomics only because they need no round trip (a plain read-modify-write would
+        // put an L2 latency at the very end of the kernel); with one add per address the result is order-free
+        atomicAdd(a.u_prev + p, su);
+        if (INC) atomicAdd(a.v + p, su);  // the source moves u' and v' alike
+        if (Q) atomicAdd(a.q_out + a.inj_cidx[i], sq);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // POINT kernel: one thread per grid point, all 4r+... neighbours straight from
 // global memory (L1/L2 absorb the re-reads).  Generic in dtype, order and
@@ -111,12 +139,7 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
         const int s0 = a.inj_start[blockIdx.x], s1 = a.inj_start[blockIdx.x + 1];
         if (s1 > s0) {
             __syncthreads();
-            for (int i = s0 + tid; i < s1; i += 256) {
-                const T amp = a.inj_amp[a.inj_col[i]];
-                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
-                if (INC) atomicAdd(a.v + a.inj_pidx[i], a.inj_cu[i] * amp);  // the source moves u' and v' alike
-                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
-            }
+            inject_runs<T, INC, SAVE_Q>(a, s0, s1, tid, 256);
         }
     }
 }
@@ -491,14 +514,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
         if (s1 > s0) {
             __syncthreads();
-            for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
-                const T amp = a.inj_amp[a.inj_col[i]];
-                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
-                if (INC) atomicAdd(a.v + a.inj_pidx[i], a.inj_cu[i] * amp);  // the source moves u' and v' alike
-                // (bf16 store: the source's own share of the imaging term is added in closed form after the adjoint
-                // sweep, source_image_kernel, instead of being rounded into the store)
-                if (SAVE_Q && !QB) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
-            }
+            // (bf16 store: the source's own share of the imaging term is added in closed form after the adjoint
+            // sweep, source_image_kernel, instead of being rounded into the store)
+            inject_runs<T, INC, SAVE_Q && !QB>(a, s0, s1, ty * 64 + lane, 64 * TY);
         }
     }
 }
@@ -620,11 +638,7 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
         const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
         if (s1 > s0) {
             __syncthreads();
-            for (int i = s0 + ty * 64 + lane; i < s1; i += 64 * TY) {
-                const float amp = a.inj_amp[a.inj_col[i]];
-                atomicAdd(a.u_prev + a.inj_pidx[i], a.inj_cu[i] * amp);
-                if (SAVE_Q) atomicAdd(a.q_out + a.inj_cidx[i], a.inj_cq[i] * amp);
-            }
+            inject_runs<float, false, SAVE_Q>(a, s0, s1, ty * 64 + lane, 64 * TY);
         }
     }
 }
