@@ -724,7 +724,8 @@ struct Impl {
             for (int done = 0; done < count; done += FUSED2D_STEPS) {
                 Fused2dArgs a{};
                 a.u_cur = (const float *)sw.f[sw.cur];
-                a.u_prev = (const float *)sw.f[sw.cur ^ 1];
+                a.u_prev = (const float *)(ctx->inc ? sw.v : sw.f[sw.cur ^ 1]);  // increment form: v in / v out
+                a.inc = ctx->inc ? 1 : 0;
                 a.C = (const float *)ctx->C;
                 a.out_cur = (float *)spare[0];
                 a.out_prev = (float *)spare[1];
@@ -761,6 +762,16 @@ struct Impl {
                     a.nrec = out->n;
                 }
                 HIPCHK(ctx, launch_fused2d(g, a, ctx->stream));
+                if (ctx->inc) {
+                    // (u, v) written into the spare pair; the old u and v buffers become the next launch's output.
+                    // The second u buffer of the sweep (the single-step kernels' output) is not involved.
+                    void *ou = sw.f[sw.cur], *ov = sw.v;
+                    sw.f[sw.cur] = spare[0];
+                    sw.v = spare[1];
+                    spare[0] = ou;
+                    spare[1] = ov;
+                    continue;
+                }
                 // the freshly written pair becomes current; the old pair is the next launch's output
                 void *oc = sw.f[sw.cur], *op = sw.f[sw.cur ^ 1];
                 sw.f[0] = spare[0];
@@ -990,6 +1001,7 @@ struct Impl {
             ctx->u[1] = sw.f[1];
             ctx->fx[0] = spare[0];
             ctx->fx[1] = spare[1];
+            if (ctx->inc) ctx->vf = sw.v;
         }
         if ((rc = download_samples(ctx, (nrec && seis_out) ? seis_out : nullptr, ctx->series, nt, nrec, ctx->rec_sp,
                                    &ctx->pts_d, &ctx->cap_pts_d)))
@@ -1057,6 +1069,7 @@ struct Impl {
             Sweep fw;
             fw.f[0] = ctx->fwd[0];
             fw.f[1] = ctx->fwd[1];
+            fw.v = ctx->fwv;
             void *fspare[2] = {ctx->fwx[0], ctx->fwx[1]};
             const int nseg = (nt + K - 1) / K;
             for (int seg = nseg - 1; seg >= 0; --seg) {
@@ -1064,7 +1077,7 @@ struct Impl {
                 const T *sn = (const T *)ctx->snap + (size_t)seg * 2 * g.ptot;
                 fw.cur = 0;
                 HIPCHK(ctx, hipMemcpyAsync(fw.f[0], sn, (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
-                HIPCHK(ctx, hipMemcpyAsync(fw.f[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
+                HIPCHK(ctx, hipMemcpyAsync(ctx->inc ? fw.v : fw.f[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));
                 T *qb = q_store - (size_t)n0 * g.npts;  // slot (n - n0) == qb + n * npts
                 if ((rc = run_fused(ctx, fw, fspare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr,
@@ -1078,6 +1091,7 @@ struct Impl {
             ctx->fwd[1] = fw.f[1];
             ctx->fwx[0] = fspare[0];
             ctx->fwx[1] = fspare[1];
+            if (ctx->inc) ctx->fwv = fw.v;
             imaged_all = true;
         } else if (fused) {
             if ((rc = run_fused(ctx, sw, spare, nt - 1, -1, nt, ctx->rec, amp, &ctx->src, series, rs, image ? 2 : 0,
@@ -1146,6 +1160,7 @@ struct Impl {
             ctx->u[1] = sw.f[1];
             ctx->fx[0] = spare[0];
             ctx->fx[1] = spare[1];
+            if (ctx->inc) ctx->vf = sw.v;
         }
         if ((rc = flush_record(ctx, sw, ctx->src, series, rs))) return rc;
         if (image && !imaged_all)  // the last pairing: mu^1 with q^0
@@ -1347,7 +1362,8 @@ const char *fwi_last_error(const fwi_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 const char *fwi_kernel_name(const fwi_ctx *ctx) {
     if (!ctx) return "";
-    if (ctx->kernel == K_STREAM && ctx->gd.ndim == 2) return ctx->fused2d ? "step2d_fused" : "step2d_tile";
+    if (ctx->fused2d) return "step2d_fused";
+    if (ctx->kernel == K_STREAM && ctx->gd.ndim == 2) return "step2d_tile";
     if (ctx->kernel == K_STREAM) return "step3d_stream";
     return "step_point";
 }
@@ -1439,8 +1455,10 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // 2-D fp32 grids: advance FUSED2D_STEPS time steps per launch (fwi_fused2d.hip) whenever the step
     // count allows it (FWI_NO_FUSED2D is the tuning / comparison hook)
     // (the CPML's slab kernels run between time steps: one step per launch, the tile kernel)
-    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml &&
-                   !getenv("FWI_NO_FUSED2D");
+    // Increment form in 2-D: the fused kernel carries it (same traffic as the standard form); the steps it cannot take
+    // (step counts off the multiple of 4) go through the point kernel, which ctx->kernel names in that case.
+    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && !ctx->cpml && !getenv("FWI_NO_FUSED2D") &&
+                   (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
     // =1 is the tuning / comparison hook)
     if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {

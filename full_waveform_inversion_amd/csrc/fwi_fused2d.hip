@@ -67,7 +67,10 @@ __device__ unsigned long long fwi_fused2d_stamps[4096 * 8];
 // the final stores use a second, fixed map of the FT x FT interior.  Register pressure decides everything at
 // 1024 threads (128 VGPRs): the update writes each group back at once (holding a thread's groups to write
 // them together spilled, and a scratch reload waits for vmcnt(0), i.e. for every load in flight).
-template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE>
+// INC: increment form (fwi_config.update_form): the second field is v = u - u_prev instead of u_prev; v' = A (B v + q),
+// u' = u + v'.  The tile then holds u twice (ping-pong: u' cannot overwrite u while neighbours still read it), v and C
+// = four LDS images (148 KB); HBM traffic is the same as in the standard form (u, v, C in; u, v out).
+template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE, bool INC>
 __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
     constexpr int FNT = 1024;  // all modes fit the 128-VGPR cap of 1024 threads (68 - 102 VGPRs, no scratch)
     constexpr int HL = (KS * R + 3) / 4 * 4;  // halo cells per side (float4 aligned)
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
     __shared__ q4 fa[E][E4];             // field A (starts as u^n)
     __shared__ q4 fb[E][E4];             // field B (starts as u^{n-1})
     __shared__ q4 fc[E][E4];             // C = dt^2 c^2, 0 outside the grid
+    __shared__ q4 fv[INC ? E : 1][E4];   // increment form: v (fb is then only the second u image)
     __shared__ float dzs[E];             // damping profiles of the tile's rows ...
     __shared__ q4 dxs4[E4];              // ... and columns (read one 16-byte group at a time: conflict-free)
 
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
                 const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
                 const int64_t p = g.off0 + (int64_t)zc * g.sz + xc;
                 __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_cur + p), (lptr_t *)(&fa[0][0] + g0), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_prev + p), (lptr_t *)(&fb[0][0] + g0), 16, 0, 0);
+                // (increment form: the "u_prev" argument is the v field)
+                __builtin_amdgcn_global_load_lds((gptr_t *)(a.u_prev + p), (lptr_t *)((INC ? &fv[0][0] : &fb[0][0]) + g0), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((gptr_t *)(a.C + p), (lptr_t *)(&fc[0][0] + g0), 16, 0, 0);
             }
         }
@@ -203,20 +208,30 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
                     lap.v[j] = fmaf(ck, t, lap.v[j]);
                 }
             }
-            const q4 up = prv[lz][l4], Cc = fc[lz][l4];
-            q4 q, un, dxv;
+            const q4 up = INC ? fv[INC ? lz : 0][l4] : prv[lz][l4], Cc = fc[lz][l4];
+            q4 q, un, vn, dxv;
             if (DAMP) dxv = dxs4[l4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 q.v[j] = Cc.v[j] * lap.v[j];
-                if (DAMP) {
+                if (INC) {
+                    if (DAMP) {
+                        const float d = dzs[lz] + dxv.v[j];
+                        vn.v[j] = fmaf(1.f - d, up.v[j], q.v[j]) * rcp1(1.f + d);
+                    } else {
+                        vn.v[j] = up.v[j] + q.v[j];
+                    }
+                    un.v[j] = c.v[j] + vn.v[j];
+                } else if (DAMP) {
                     const float d = dzs[lz] + dxv.v[j];
                     un.v[j] = (fmaf(2.f, c.v[j], -(1.f - d) * up.v[j]) + q.v[j]) * rcp1(1.f + d);
                 } else {
                     un.v[j] = (2.f * c.v[j] - up.v[j]) + q.v[j];
                 }
             }
-            prv[lz][l4] = un;  // in place: only this thread reads prv[lz][l4]
+            if (INC) fv[INC ? lz : 0][l4] = vn;  // in place: only this thread touches v here
+            prv[lz][l4] = un;  // standard form: in place over u_prev (only this thread reads it); increment form: the
+                               // other u image, which nobody reads in this sub-step
             if (SAVE_Q && qstep) {
                 const int z = z0 + lz, x = x0 + 4 * l4;
                 const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
@@ -243,6 +258,7 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
                     sq += a.inj_cq[j] * amp;
                 }
                 atomicAdd(&prv[lz][lx >> 2].v[lx & 3], su);  // (one ds_add per node: no read-back latency)
+                if (INC) atomicAdd(&fv[INC ? lz : 0][lx >> 2].v[lx & 3], su);  // the source moves u' and v' alike
                 if (SAVE_Q && qstep && a.inj_interior[i]) atomicAdd(qslot + a.inj_cidx[i], sq);  // (no round trip)
             }
             __syncthreads();
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
         // a group straddling the right edge writes zeros into the pad columns: they are zero by construction
         const int64_t p = g.off0 + (int64_t)z * g.sz + x;
         *reinterpret_cast<q4 *>(a.out_cur + p) = cur[lz][l4];
-        *reinterpret_cast<q4 *>(a.out_prev + p) = prv[lz][l4];
+        *reinterpret_cast<q4 *>(a.out_prev + p) = INC ? fv[INC ? lz : 0][l4] : prv[lz][l4];  // u^{n+K-1}, or v^{n+K}
         if (IMAGE) {
             float *gp = a.g + (int64_t)z * g.cx + x;
             q4 gv = *reinterpret_cast<const q4 *>(gp);
@@ -322,12 +338,19 @@ template <int R, bool DAMP>
 static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
     constexpr int KS = FUSED2D_STEPS, FT = FUSED2D_TILE;
     const dim3 grid(fused2d_num_tiles(g));
-    if (a.mode == 1)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false>), grid, dim3(1024), 0, s, a, g);
+    if (a.inc) {
+        if (a.mode == 1)
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, true>), grid, dim3(1024), 0, s, a, g);
+        else if (a.mode == 2)
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, true>), grid, dim3(1024), 0, s, a, g);
+        else
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, true>), grid, dim3(1024), 0, s, a, g);
+    } else if (a.mode == 1)
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, false>), grid, dim3(1024), 0, s, a, g);
     else if (a.mode == 2)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true>), grid, dim3(1024), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, false>), grid, dim3(1024), 0, s, a, g);
     else
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false>), grid, dim3(1024), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, false>), grid, dim3(1024), 0, s, a, g);
     return hipGetLastError();
 }
 

@@ -167,6 +167,7 @@ struct Fused2dArgs {
     float *g;                          // compact gradient accumulator (mode 2)
     int n0, dn;                        // first step index of the launch and +1 / -1
     int xcd_remap;                     // set by launch_fused2d: XCD-contiguous tile numbering
+    int inc;                           // increment form: u_prev / out_prev are the v field in / out
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
     const int *inj_start, *inj_lz, *inj_lx, *inj_col;
     const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)

@@ -70,8 +70,8 @@ def main():
         case("cfg5 64^3 x250", workloads.cfg5(0.25)),
         case("cfg5 128^3 x500", workloads.cfg5(0.5)),
         # the fp32 increment-form update (fwi_config.update_form = 1) beside the standard form above
-        case("cfg2 512^2 x1000 increment (point kernel)", workloads.cfg2(0.5), update_form="increment"),
-        case("cfg2 1024^2 x2000 (full) increment (point kernel)", workloads.cfg2(1.0), update_form="increment"),
+        case("cfg2 512^2 x1000 increment", workloads.cfg2(0.5), update_form="increment"),
+        case("cfg2 1024^2 x2000 (full) increment", workloads.cfg2(1.0), update_form="increment"),
         case("cfg4 128^3 x500 increment", workloads.cfg4(0.5), update_form="increment"),
         case("cfg5 64^3 x250 increment", workloads.cfg5(0.25), update_form="increment"),
         case("cfg5 128^3 x500 increment", workloads.cfg5(0.5), update_form="increment"),
