@@ -90,8 +90,8 @@ typedef struct fwi_config {
                               recursion carried as (u, v = u - u_prev): v' = A (B v + q), u' = u + v'.  In fp32 the
                               round-off of the standard form is amplified by ~1 / (omega dt) (the cancellation in
                               2u - u_prev); the increment form rounds u' relative to u: ~4x smaller errors on
-                              seismograms and gradient at 20 instead of 16 B/update.  Kernels: 3-D stream (fp32)
-                              and the point kernel; a 2-D grid runs on the point kernel in this form. */
+                              seismograms and gradient.  Kernels: 3-D stream (fp32; 20 instead of 16 B/update),
+                              2-D fused (fp32; same traffic, the tile holds u twice, v and C) and the point kernel. */
     int32_t abc;          /* absorbing boundary of the npml border: FWI_ABC_SPONGE (damping factors A, B) or
                               FWI_ABC_CPML (convolutional PML: memory variables in the border only) */
     int32_t store_dtype;  /* forward-term store: FWI_STORE_NATIVE (the field type) or FWI_STORE_BF16 (fp32 contexts:
