@@ -52,50 +52,54 @@ __device__ __forceinline__ T aux_at(const T *aux, const AxisView<T> &v, int64_t 
 
 }  // namespace
 
-// One thread per point of the region: the border of axis d (phase 1, 2) or the border widened by R (phase 3).
-// dims of the region: (e0, e1, e2) = (z, y, x) extents with the d extent replaced by the region's plane count.
-template <typename T, int R>
-__global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g, int phase, int d, int reverse) {
+// One thread per point of the region: the border of axis D (phase 1, 2) or the border widened by R (phase 3).
+// Launch geometry: x along threadIdx.x (and blockIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z --
+// with the D extent replaced by the region's plane count -- so no thread divides anything; axis, phase and direction
+// are compile-time (the first form decoded a linear index with two 64-bit divisions per thread and branched on all
+// three at run time: 2-3 TB/s; see DESIGN.md s.4 CPML).
+template <typename T, int R, int D, int PHASE, bool REV>
+__global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
     const int nd[3] = {g.nz, g.ny, g.nx};
-    const int n = nd[d], npml = p.npml;
+    const int n = nd[D], npml = p.npml;
     const int nslab = min(n, 2 * npml);
     const int wide = min(n, 2 * (npml + R));  // planes of the widened region
-    const int ext = phase == 3 ? wide : nslab;
     int e[3] = {g.nz, g.ny, g.nx};
-    e[d] = ext;
-    const int64_t total = (int64_t)e[0] * e[1] * e[2];
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= total) return;
+    e[D] = PHASE == 3 ? wide : nslab;
     int c[3];
-    c[2] = (int)(t % e[2]);
-    c[1] = (int)((t / e[2]) % e[1]);
-    c[0] = (int)(t / ((int64_t)e[2] * e[1]));
-    // grid coordinate along d
-    const int jd = c[d];
+    c[2] = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g.ndim == 3) {
+        c[1] = blockIdx.y * blockDim.y + threadIdx.y;
+        c[0] = blockIdx.z;
+    } else {  // 2-D: the block's second dimension runs over z
+        c[1] = 0;
+        c[0] = blockIdx.z * blockDim.y + threadIdx.y;
+    }
+    if (c[2] >= e[2] || c[1] >= e[1] || c[0] >= e[0]) return;
+    // grid coordinate along D
+    const int jd = c[D];
     int i;
-    if (phase == 3)
+    if (PHASE == 3)
         i = (n <= 2 * (npml + R) || jd < npml + R) ? jd : n - 2 * (npml + R) + jd;
     else
         i = slab_to_grid(jd, n, npml);
     int gc[3] = {c[0], c[1], c[2]};
-    gc[d] = i;
-    const int64_t gstr[3] = {g.sz, g.sy, 1};
+    gc[D] = i;
+    const int64_t gs = D == 0 ? g.sz : D == 1 ? g.sy : 1;                              // field stride along D
     const int64_t pp = g.off0 + (int64_t)gc[0] * g.sz + (int64_t)gc[1] * g.sy + gc[2];  // padded index
-    // compact aux arrays of axis d: extents (nz, ny, nx) with the d extent = nslab, x fastest
+    // compact aux arrays of axis D: extents (nz, ny, nx) with the D extent = nslab, x fastest
     int ae[3] = {g.nz, g.ny, g.nx};
-    ae[d] = nslab;
+    ae[D] = nslab;
     const int64_t astr[3] = {(int64_t)ae[1] * ae[2], ae[2], 1};
     int ac[3] = {gc[0], gc[1], gc[2]};
-    ac[d] = 0;
+    ac[D] = 0;
     const int64_t abase = (int64_t)ac[0] * astr[0] + (int64_t)ac[1] * astr[1] + ac[2];  // aux offset at slab plane 0
-    AxisView<T> v{d, n, npml, gstr[d], astr[d], p.a[d], p.b[d]};
-    T *psi = p.psi[d], *zet = p.zeta[d];
+    AxisView<T> v{D, n, npml, gs, astr[D], p.a[D], p.b[D]};
+    T *psi = p.psi[D], *zet = p.zeta[D];
     const T *u = p.u_cur + pp;
-    const int64_t gs = v.gst;
 
-    if (phase == 1) {
+    if (PHASE == 1) {
         const int64_t ai = abase + (int64_t)jd * v.ast;
-        if (!reverse) {
+        if (!REV) {
             T du = T(0);
 #pragma unroll
             for (int k = 1; k <= R; ++k) du = fma(p.dk[k], u[k * gs] - u[-k * gs], du);
@@ -103,9 +107,9 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g, int 
         } else {
             zet[ai] = fma(v.b[i], zet[ai], u[0]);
         }
-    } else if (phase == 2) {
+    } else if (PHASE == 2) {
         const int64_t ai = abase + (int64_t)jd * v.ast;
-        if (!reverse) {
+        if (!REV) {
             T e2 = p.ck[0] * u[0], dp = T(0);
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g, int 
         }
     } else {
         T term;
-        if (!reverse) {
+        if (!REV) {
             T dp = T(0);
 #pragma unroll
             for (int k = 1; k <= R; ++k)
@@ -152,20 +156,37 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g, int 
     }
 }
 
+template <typename T, int R, int D, int PHASE>
+static void launch_pml_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
+    const int nd[3] = {g.nz, g.ny, g.nx};
+    int e[3] = {g.nz, g.ny, g.nx};
+    e[D] = PHASE == 3 ? std::min(nd[D], 2 * (p.npml + R)) : std::min(nd[D], 2 * p.npml);
+    if (e[0] <= 0 || e[1] <= 0 || e[2] <= 0) return;
+    // threads along x: a 32-wide block for thin x slabs and narrow grids, 256-wide otherwise
+    const int bx = e[2] <= 32 ? 32 : e[2] <= 96 ? 64 : 256, by = 256 / bx;
+    const dim3 block(bx, by);
+    const dim3 grid((e[2] + bx - 1) / bx, g.ndim == 3 ? (e[1] + by - 1) / by : 1, g.ndim == 3 ? e[0] : (e[0] + by - 1) / by);
+    if (reverse)
+        hipLaunchKernelGGL((pml_kernel<T, R, D, PHASE, true>), grid, block, 0, s, p, g);
+    else
+        hipLaunchKernelGGL((pml_kernel<T, R, D, PHASE, false>), grid, block, 0, s, p, g);
+}
+
+template <typename T, int R, int PHASE>
+static hipError_t launch_pml_phase(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
+    launch_pml_axis<T, R, 0, PHASE>(g, p, reverse, s);
+    if (g.ndim == 3) launch_pml_axis<T, R, 1, PHASE>(g, p, reverse, s);
+    launch_pml_axis<T, R, 2, PHASE>(g, p, reverse, s);
+    return hipGetLastError();
+}
+
 template <typename T, int R>
 static hipError_t launch_pml_r(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
-    const int nd[3] = {g.nz, g.ny, g.nx};
-    for (int d = 0; d < 3; ++d) {
-        if (d == 1 && g.ndim == 2) continue;
-        const int ext = phase == 3 ? std::min(nd[d], 2 * (p.npml + R)) : std::min(nd[d], 2 * p.npml);
-        int64_t total = ext;
-        for (int o = 0; o < 3; ++o)
-            if (o != d) total *= nd[o];
-        if (total <= 0) continue;
-        hipLaunchKernelGGL((pml_kernel<T, R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, g, phase, d,
-                           reverse);
+    switch (phase) {
+        case 1: return launch_pml_phase<T, R, 1>(g, p, reverse, s);
+        case 2: return launch_pml_phase<T, R, 2>(g, p, reverse, s);
+        default: return launch_pml_phase<T, R, 3>(g, p, reverse, s);
     }
-    return hipGetLastError();
 }
 
 template <typename T>
