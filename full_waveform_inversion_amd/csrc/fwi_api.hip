@@ -1307,9 +1307,9 @@ int create_impl(fwi_ctx *ctx) {
         for (int d = 0; d < 3; ++d) {
             if (d == 1 && g.ndim == 2) continue;
             const int n = nd[d], nslab = std::min(n, 2 * c.npml);
-            size_t cnt = (size_t)nslab;
+            size_t cnt = (size_t)nslab;  // rows padded to cx (16-byte lanes of the z / y border kernels)
             for (int o = 0; o < 3; ++o)
-                if (o != d) cnt *= (size_t)nd[o];
+                if (o != d) cnt *= (size_t)(o == 2 ? g.cx : nd[o]);
             ctx->pml_bytes[d] = cnt * es;
             HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d]));
             HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d]));

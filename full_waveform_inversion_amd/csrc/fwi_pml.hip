@@ -42,31 +42,48 @@ struct AxisView {
     const T *a, *b;   // 1-D coefficients (length n)
 };
 
-// value of a memory variable at grid index i along d (0 outside the border), given the aux offset of the other
+// VL consecutive x values of one thread: 16 bytes (float4 / double2) for the z and y borders, whose rows run along
+// x; one value for the x border.  Memory-variable rows are padded to cx (a multiple of 4) so the vectors stay aligned
+// for any nx; the pad columns hold zeros (u = 0 and C = 0 there).
+template <typename T, int VL>
+struct alignas(sizeof(T) * VL) vecn {
+    T v[VL];
+};
+template <typename T, int VL>
+__device__ __forceinline__ vecn<T, VL> ldn(const T *p) { return *reinterpret_cast<const vecn<T, VL> *>(p); }
+template <typename T, int VL>
+__device__ __forceinline__ void stn(T *p, const vecn<T, VL> &x) { *reinterpret_cast<vecn<T, VL> *>(p) = x; }
+
+// VL values of a memory variable at grid index i along d (0 outside the border), given the aux offset of the other
 // two coordinates
-template <typename T>
-__device__ __forceinline__ T aux_at(const T *aux, const AxisView<T> &v, int64_t base, int i) {
+template <typename T, int VL>
+__device__ __forceinline__ vecn<T, VL> aux_at(const T *aux, const AxisView<T> &v, int64_t base, int i) {
     const int j = grid_to_slab(i, v.n, v.npml);
-    return j < 0 ? T(0) : aux[base + (int64_t)j * v.ast];
+    vecn<T, VL> z;
+#pragma unroll
+    for (int q = 0; q < VL; ++q) z.v[q] = T(0);
+    return j < 0 ? z : ldn<T, VL>(aux + base + (int64_t)j * v.ast);
 }
 
 }  // namespace
 
-// One thread per point of the region: the border of axis D (phase 1, 2) or the border widened by R (phase 3).
+// One thread per VL points of the region: the border of axis D (phase 1, 2) or the border widened by R (phase 3).
 // Launch geometry: x along threadIdx.x (and blockIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z --
 // with the D extent replaced by the region's plane count -- so no thread divides anything; axis, phase and direction
 // are compile-time (the first form decoded a linear index with two 64-bit divisions per thread and branched on all
-// three at run time: 2-3 TB/s; see DESIGN.md s.4 CPML).
+// three at run time; see DESIGN.md s.4 CPML).
 template <typename T, int R, int D, int PHASE, bool REV>
 __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
+    constexpr int VL = D == 2 ? 1 : (int)(16 / sizeof(T));
+    using V = vecn<T, VL>;
     const int nd[3] = {g.nz, g.ny, g.nx};
     const int n = nd[D], npml = p.npml;
     const int nslab = min(n, 2 * npml);
     const int wide = min(n, 2 * (npml + R));  // planes of the widened region
-    int e[3] = {g.nz, g.ny, g.nx};
+    int e[3] = {g.nz, g.ny, D == 2 ? g.nx : g.cx};  // (x extent in padded-row terms for the vector lanes)
     e[D] = PHASE == 3 ? wide : nslab;
     int c[3];
-    c[2] = blockIdx.x * blockDim.x + threadIdx.x;
+    c[2] = VL * (blockIdx.x * blockDim.x + threadIdx.x);
     if (g.ndim == 3) {
         c[1] = blockIdx.y * blockDim.y + threadIdx.y;
         c[0] = blockIdx.z;
@@ -86,8 +103,8 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
     gc[D] = i;
     const int64_t gs = D == 0 ? g.sz : D == 1 ? g.sy : 1;                              // field stride along D
     const int64_t pp = g.off0 + (int64_t)gc[0] * g.sz + (int64_t)gc[1] * g.sy + gc[2];  // padded index
-    // compact aux arrays of axis D: extents (nz, ny, nx) with the D extent = nslab, x fastest
-    int ae[3] = {g.nz, g.ny, g.nx};
+    // compact aux arrays of axis D: extents (nz, ny, cx) with the D extent = nslab, x fastest
+    int ae[3] = {g.nz, g.ny, g.cx};
     ae[D] = nslab;
     const int64_t astr[3] = {(int64_t)ae[1] * ae[2], ae[2], 1};
     int ac[3] = {gc[0], gc[1], gc[2]};
@@ -96,70 +113,140 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
     AxisView<T> v{D, n, npml, gs, astr[D], p.a[D], p.b[D]};
     T *psi = p.psi[D], *zet = p.zeta[D];
     const T *u = p.u_cur + pp;
+    auto U = [&](int k) { return ldn<T, VL>(u + k * gs); };  // (aligned: pp, gs and k * gs keep x % VL == 0 for D != 2)
 
     if (PHASE == 1) {
         const int64_t ai = abase + (int64_t)jd * v.ast;
+        V out = ldn<T, VL>((REV ? zet : psi) + ai);
         if (!REV) {
-            T du = T(0);
+            V du;
 #pragma unroll
-            for (int k = 1; k <= R; ++k) du = fma(p.dk[k], u[k * gs] - u[-k * gs], du);
-            psi[ai] = fma(v.b[i], psi[ai], v.a[i] * du);
+            for (int q = 0; q < VL; ++q) du.v[q] = T(0);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const V up = U(k), um = U(-k);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) du.v[q] = fma(p.dk[k], up.v[q] - um.v[q], du.v[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < VL; ++q) out.v[q] = fma(v.b[i], out.v[q], v.a[i] * du.v[q]);
+            stn<T, VL>(psi + ai, out);
         } else {
-            zet[ai] = fma(v.b[i], zet[ai], u[0]);
+            const V u0 = U(0);
+#pragma unroll
+            for (int q = 0; q < VL; ++q) out.v[q] = fma(v.b[i], out.v[q], u0.v[q]);
+            stn<T, VL>(zet + ai, out);
         }
     } else if (PHASE == 2) {
         const int64_t ai = abase + (int64_t)jd * v.ast;
         if (!REV) {
-            T e2 = p.ck[0] * u[0], dp = T(0);
+            const V u0 = U(0);
+            V e2, dp;
+#pragma unroll
+            for (int q = 0; q < VL; ++q) {
+                e2.v[q] = p.ck[0] * u0.v[q];
+                dp.v[q] = T(0);
+            }
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
-                e2 = fma(p.ck[k], u[k * gs] + u[-k * gs], e2);
-                dp = fma(p.dk[k], aux_at(psi, v, abase, i + k) - aux_at(psi, v, abase, i - k), dp);
+                const V up = U(k), um = U(-k);
+                const V pp_ = aux_at<T, VL>(psi, v, abase, i + k), pm = aux_at<T, VL>(psi, v, abase, i - k);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    e2.v[q] = fma(p.ck[k], up.v[q] + um.v[q], e2.v[q]);
+                    dp.v[q] = fma(p.dk[k], pp_.v[q] - pm.v[q], dp.v[q]);
+                }
             }
-            zet[ai] = fma(v.b[i], zet[ai], v.a[i] * (e2 + dp));
+            V z = ldn<T, VL>(zet + ai);
+#pragma unroll
+            for (int q = 0; q < VL; ++q) z.v[q] = fma(v.b[i], z.v[q], v.a[i] * (e2.v[q] + dp.v[q]));
+            stn<T, VL>(zet + ai, z);
         } else {
-            T du = T(0), da = T(0);
+            V du, da;
+#pragma unroll
+            for (int q = 0; q < VL; ++q) du.v[q] = da.v[q] = T(0);
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
-                du = fma(p.dk[k], u[k * gs] - u[-k * gs], du);
+                const V up = U(k), um = U(-k);
                 const int ip = i + k, im = i - k;
-                const T ap = (ip < n) ? v.a[ip] * aux_at(zet, v, abase, ip) : T(0);
-                const T am = (im >= 0) ? v.a[im] * aux_at(zet, v, abase, im) : T(0);
-                da = fma(p.dk[k], ap - am, da);
+                const T ap = (ip < n) ? v.a[ip] : T(0), am = (im >= 0) ? v.a[im] : T(0);
+                const V zp = aux_at<T, VL>(zet, v, abase, ip), zm = aux_at<T, VL>(zet, v, abase, im);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    du.v[q] = fma(p.dk[k], up.v[q] - um.v[q], du.v[q]);
+                    da.v[q] = fma(p.dk[k], ap * zp.v[q] - am * zm.v[q], da.v[q]);
+                }
             }
-            psi[ai] = v.b[i] * psi[ai] - du - da;
+            V ps = ldn<T, VL>(psi + ai);
+#pragma unroll
+            for (int q = 0; q < VL; ++q) ps.v[q] = v.b[i] * ps.v[q] - du.v[q] - da.v[q];
+            stn<T, VL>(psi + ai, ps);
         }
     } else {
-        T term;
+        V term;
         if (!REV) {
-            T dp = T(0);
+            const V z0 = aux_at<T, VL>(zet, v, abase, i);
 #pragma unroll
-            for (int k = 1; k <= R; ++k)
-                dp = fma(p.dk[k], aux_at(psi, v, abase, i + k) - aux_at(psi, v, abase, i - k), dp);
-            term = dp + aux_at(zet, v, abase, i);
+            for (int q = 0; q < VL; ++q) term.v[q] = z0.v[q];
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const V pp_ = aux_at<T, VL>(psi, v, abase, i + k), pm = aux_at<T, VL>(psi, v, abase, i - k);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) term.v[q] = fma(p.dk[k], pp_.v[q] - pm.v[q], term.v[q]);
+            }
         } else {
-            const int j0 = grid_to_slab(i, n, npml);
-            T e2 = (j0 >= 0) ? p.ck[0] * v.a[i] * zet[abase + (int64_t)j0 * v.ast] : T(0), db = T(0);
+            const T a0 = v.a[i];
+            const V z0 = aux_at<T, VL>(zet, v, abase, i);
+            V db;
+#pragma unroll
+            for (int q = 0; q < VL; ++q) {
+                term.v[q] = p.ck[0] * a0 * z0.v[q];
+                db.v[q] = T(0);
+            }
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const int ip = i + k, im = i - k;
                 const T ap = (ip < n) ? v.a[ip] : T(0), am = (im >= 0) ? v.a[im] : T(0);
-                e2 = fma(p.ck[k], ap * aux_at(zet, v, abase, ip) + am * aux_at(zet, v, abase, im), e2);
-                db = fma(p.dk[k], ap * aux_at(psi, v, abase, ip) - am * aux_at(psi, v, abase, im), db);
+                const V zp = aux_at<T, VL>(zet, v, abase, ip), zm = aux_at<T, VL>(zet, v, abase, im);
+                const V qp = aux_at<T, VL>(psi, v, abase, ip), qm = aux_at<T, VL>(psi, v, abase, im);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    term.v[q] = fma(p.ck[k], ap * zp.v[q] + am * zm.v[q], term.v[q]);
+                    db.v[q] = fma(p.dk[k], ap * qp.v[q] - am * qm.v[q], db.v[q]);
+                }
             }
-            term = e2 - db;
+#pragma unroll
+            for (int q = 0; q < VL; ++q) term.v[q] -= db.v[q];
         }
-        const T add = p.C[pp] * term;
-        p.u_next[pp] += add;
-        if (p.v) p.v[pp] += add;  // increment form: the step's v' = u' - u moves with u'
-        if (p.q_out) p.q_out[((int64_t)gc[0] * g.ny + gc[1]) * g.cx + gc[2]] += add;
+        const V Cc = ldn<T, VL>(p.C + pp);
+        V un = ldn<T, VL>(p.u_next + pp), add;
+#pragma unroll
+        for (int q = 0; q < VL; ++q) {
+            add.v[q] = Cc.v[q] * term.v[q];
+            un.v[q] += add.v[q];
+        }
+        stn<T, VL>(p.u_next + pp, un);
+        if (p.v) {  // increment form: the step's v' = u' - u moves with u'
+            V vv = ldn<T, VL>(p.v + pp);
+#pragma unroll
+            for (int q = 0; q < VL; ++q) vv.v[q] += add.v[q];
+            stn<T, VL>(p.v + pp, vv);
+        }
+        if (p.q_out) {
+            T *qp = p.q_out + ((int64_t)gc[0] * g.ny + gc[1]) * g.cx + gc[2];
+            V qq = ldn<T, VL>(qp);
+#pragma unroll
+            for (int q = 0; q < VL; ++q) qq.v[q] += add.v[q];
+            stn<T, VL>(qp, qq);
+        }
     }
 }
 
 template <typename T, int R, int D, int PHASE>
 static void launch_pml_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
     const int nd[3] = {g.nz, g.ny, g.nx};
-    int e[3] = {g.nz, g.ny, g.nx};
+    constexpr int VL = D == 2 ? 1 : (int)(16 / sizeof(T));
+    int e[3] = {g.nz, g.ny, D == 2 ? g.nx : g.cx / VL};  // threads along x: one per VL columns of the padded row
     e[D] = PHASE == 3 ? std::min(nd[D], 2 * (p.npml + R)) : std::min(nd[D], 2 * p.npml);
     if (e[0] <= 0 || e[1] <= 0 || e[2] <= 0) return;
     // threads along x: a 32-wide block for thin x slabs and narrow grids, 256-wide otherwise
