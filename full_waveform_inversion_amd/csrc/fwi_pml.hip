@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "fwi_kernels.h"
 
@@ -242,9 +243,140 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
     }
 }
 
+// x border, fp32, r = 4, npml and nx multiples of 4: four consecutive x per thread (one 16-byte lane), the +-4
+// neighbours from the two adjacent aligned vectors -- borders that are multiples of 4 wide start on vector boundaries,
+// so a neighbour vector is either entirely inside the border or entirely outside it (zeros).
+template <int PHASE, bool REV>
+__global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc g) {
+    constexpr int R = 4;
+    using V = vecn<float, 4>;
+    const int n = g.nx, npml = p.npml;
+    const int nslab = 2 * npml, wide = 2 * (npml + R);
+    const int ex = (PHASE == 3 ? wide : nslab) / 4;
+    const int jv = blockIdx.x * blockDim.x + threadIdx.x;
+    int y, z;
+    if (g.ndim == 3) {
+        y = blockIdx.y * blockDim.y + threadIdx.y;
+        z = blockIdx.z;
+    } else {
+        y = 0;
+        z = blockIdx.z * blockDim.y + threadIdx.y;
+    }
+    if (jv >= ex || y >= g.ny || z >= g.nz) return;
+    const int jd = 4 * jv;
+    const int half = PHASE == 3 ? npml + R : npml;
+    const int i = jd < half ? jd : n - 2 * half + jd;              // grid x of this vector's first value
+    const int64_t pp = g.off0 + (int64_t)z * g.sz + (int64_t)y * g.sy + i;
+    const int64_t abase = ((int64_t)z * g.ny + y) * nslab;          // aux row (nz, ny, nslab)
+    const float *A = p.a[2], *B = p.b[2];
+    float *psi = p.psi[2], *zet = p.zeta[2];
+    // 12 field values u[i-4 .. i+7] (the halo left of the row and the pad right of it hold zeros)
+    auto field_win = [&](float *X) {
+        const V l = ldn<float, 4>(p.u_cur + pp - 4), c = ldn<float, 4>(p.u_cur + pp), r = ldn<float, 4>(p.u_cur + pp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { X[q] = l.v[q]; X[4 + q] = c.v[q]; X[8 + q] = r.v[q]; }
+    };
+    // 12 values of a memory variable at grid x = i-4 .. i+7, optionally times a(x); zeros outside the border
+    auto aux_win = [&](const float *arr, bool times_a, float *X) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) {
+            const int ig = i - 4 + 4 * gq;
+            const int j = (ig >= 0 && ig < npml) ? ig : (ig >= n - npml && ig < n) ? ig - (n - nslab) : -1;
+            V w = {{0.f, 0.f, 0.f, 0.f}};
+            if (j >= 0) w = ldn<float, 4>(arr + abase + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X[4 * gq + q] = (times_a && j >= 0) ? A[ig + q] * w.v[q] : w.v[q];
+        }
+    };
+    const bool inb = (i >= 0 && i < npml) || (i >= n - npml && i < n);  // this vector lies in the border proper
+    const int j0 = i < npml ? i : i - (n - nslab);
+    if (PHASE == 1) {
+        V out = ldn<float, 4>((REV ? zet : psi) + abase + j0);
+        float X[12];
+        field_win(X);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!REV) {
+                float du = 0.f;
+#pragma unroll
+                for (int k = 1; k <= R; ++k) du = fmaf(p.dk[k], X[4 + q + k] - X[4 + q - k], du);
+                out.v[q] = fmaf(B[i + q], out.v[q], A[i + q] * du);
+            } else {
+                out.v[q] = fmaf(B[i + q], out.v[q], X[4 + q]);
+            }
+        }
+        stn<float, 4>((REV ? zet : psi) + abase + j0, out);
+    } else if (PHASE == 2) {
+        float X[12], Y[12];
+        field_win(X);
+        aux_win(REV ? zet : psi, REV, Y);   // forward: psi'; adjoint: a zt'
+        V out = ldn<float, 4>((REV ? psi : zet) + abase + j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float du = 0.f, dy = 0.f, e2 = p.ck[0] * X[4 + q];
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                du = fmaf(p.dk[k], X[4 + q + k] - X[4 + q - k], du);
+                e2 = fmaf(p.ck[k], X[4 + q + k] + X[4 + q - k], e2);
+                dy = fmaf(p.dk[k], Y[4 + q + k] - Y[4 + q - k], dy);
+            }
+            out.v[q] = REV ? B[i + q] * out.v[q] - du - dy : fmaf(B[i + q], out.v[q], A[i + q] * (e2 + dy));
+        }
+        stn<float, 4>((REV ? psi : zet) + abase + j0, out);
+    } else {
+        float P[12], Z[12];
+        aux_win(psi, REV, P);               // forward: psi'; adjoint: a pt'
+        aux_win(zet, REV, Z);               // forward: zeta'; adjoint: a zt'
+        const V Cc = ldn<float, 4>(p.C + pp);
+        V un = ldn<float, 4>(p.u_next + pp), add;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dp = 0.f, e2 = p.ck[0] * Z[4 + q];
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                dp = fmaf(p.dk[k], P[4 + q + k] - P[4 + q - k], dp);
+                e2 = fmaf(p.ck[k], Z[4 + q + k] + Z[4 + q - k], e2);
+            }
+            const float term = REV ? e2 - dp : dp + Z[4 + q];
+            add.v[q] = Cc.v[q] * term;
+            un.v[q] += add.v[q];
+        }
+        (void)inb;
+        stn<float, 4>(p.u_next + pp, un);
+        if (p.v) {
+            V vv = ldn<float, 4>(p.v + pp);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv.v[q] += add.v[q];
+            stn<float, 4>(p.v + pp, vv);
+        }
+        if (p.q_out) {
+            float *qp = p.q_out + ((int64_t)z * g.ny + y) * g.cx + i;
+            V qq = ldn<float, 4>(qp);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qq.v[q] += add.v[q];
+            stn<float, 4>(qp, qq);
+        }
+    }
+}
+
 template <typename T, int R, int D, int PHASE>
 static void launch_pml_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
     const int nd[3] = {g.nz, g.ny, g.nx};
+    if constexpr (D == 2 && R == 4 && std::is_same<T, float>::value) {
+        // 16-byte lanes along the x border too when everything starts on vector boundaries
+        if (p.npml % 4 == 0 && g.nx % 4 == 0 && g.nx >= 2 * (p.npml + R)) {
+            const int ex = (PHASE == 3 ? 2 * (p.npml + R) : 2 * p.npml) / 4;
+            const int bx = ex <= 8 ? 8 : 16, by = 256 / bx;
+            const dim3 block(bx, by);
+            const dim3 grid((ex + bx - 1) / bx, g.ndim == 3 ? (g.ny + by - 1) / by : 1,
+                            g.ndim == 3 ? g.nz : (g.nz + by - 1) / by);
+            if (reverse)
+                hipLaunchKernelGGL((pml_kernel_x4<PHASE, true>), grid, block, 0, s, p, g);
+            else
+                hipLaunchKernelGGL((pml_kernel_x4<PHASE, false>), grid, block, 0, s, p, g);
+            return;
+        }
+    }
     constexpr int VL = D == 2 ? 1 : (int)(16 / sizeof(T));
     int e[3] = {g.nz, g.ny, D == 2 ? g.nx : g.cx / VL};  // threads along x: one per VL columns of the padded row
     e[D] = PHASE == 3 ? std::min(nd[D], 2 * (p.npml + R)) : std::min(nd[D], 2 * p.npml);

@@ -18,6 +18,9 @@ def rel(a, b):
 CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {}),
     ((33, 29, 50), 4, 5, 0.0, "float32", TOL32, "step3d_stream", {}),
+    ((36, 30, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {}),    # npml, nx multiples of 4: 16-byte lanes on x too
+    ((30, 26, 24), 8, 8, 0.0, "float32", TOL32, "step3d_stream", {}),     # ... with the two x borders back to back
+    ((72, 96), 8, 12, 40.0, "float32", TOL32, "step2d_tile", {}),
     ((40, 36, 44), 8, 6, 30.0, "float64", TOL64, "step3d_stream", {}),
     ((22, 9, 30), 2, 5, 20.0, "float64", TOL64, "step3d_stream", {}),     # ny < 2 npml: the y borders overlap
     ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {"update_form": "increment"}),
