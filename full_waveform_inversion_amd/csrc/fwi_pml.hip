@@ -10,6 +10,8 @@
 //   K2  zeta <- b zeta + a (E u + D psi)      pt <- b pt - D mu - D (a zt)
 //   --- the step kernel: u' = 2u - u_prev + C (L u + injection) ---
 //   K3  u' += C (D psi + zeta)  [q too]       u' += C (E (a zt) - D (a pt))
+// (forward: K2 rides along in K3's launch -- both need D psi', zeta' only its own point -- so a step is 1 + 2 x axes
+// launches forward and 1 + 3 x axes in the adjoint sweep, where pt' feeds K3 through its neighbours)
 //
 // D = centred first difference, E = second-difference star along d.  K3 covers the border widened by the stencil
 // radius (D psi reaches that far).  These are bandwidth-trivial kernels over <= 2 (npml + r) planes per axis.
@@ -186,14 +188,37 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
     } else {
         V term;
         if (!REV) {
-            const V z0 = aux_at<T, VL>(zet, v, abase, i);
+            // forward: phase 2 rides along (zeta' needs the same D psi' and only this point's own zeta)
+            V dp;
 #pragma unroll
-            for (int q = 0; q < VL; ++q) term.v[q] = z0.v[q];
+            for (int q = 0; q < VL; ++q) dp.v[q] = T(0);
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const V pp_ = aux_at<T, VL>(psi, v, abase, i + k), pm = aux_at<T, VL>(psi, v, abase, i - k);
 #pragma unroll
-                for (int q = 0; q < VL; ++q) term.v[q] = fma(p.dk[k], pp_.v[q] - pm.v[q], term.v[q]);
+                for (int q = 0; q < VL; ++q) dp.v[q] = fma(p.dk[k], pp_.v[q] - pm.v[q], dp.v[q]);
+            }
+            term = dp;
+            const int j0 = grid_to_slab(i, n, npml);
+            if (j0 >= 0) {
+                const V u0 = U(0);
+                V e2;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) e2.v[q] = p.ck[0] * u0.v[q];
+#pragma unroll
+                for (int k = 1; k <= R; ++k) {
+                    const V up = U(k), um = U(-k);
+#pragma unroll
+                    for (int q = 0; q < VL; ++q) e2.v[q] = fma(p.ck[k], up.v[q] + um.v[q], e2.v[q]);
+                }
+                const int64_t ai = abase + (int64_t)j0 * v.ast;
+                V z = ldn<T, VL>(zet + ai);
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    z.v[q] = fma(v.b[i], z.v[q], v.a[i] * (e2.v[q] + dp.v[q]));
+                    term.v[q] += z.v[q];
+                }
+                stn<T, VL>(zet + ai, z);
             }
         } else {
             const T a0 = v.a[i];
@@ -326,7 +351,10 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
     } else {
         float P[12], Z[12];
         aux_win(psi, REV, P);               // forward: psi'; adjoint: a pt'
-        aux_win(zet, REV, Z);               // forward: zeta'; adjoint: a zt'
+        if (REV) aux_win(zet, true, Z);     // adjoint: a zt'
+        else field_win(Z);                  // forward: u (phase 2 rides along: zeta' = b zeta + a (E u + D psi'))
+        V zn = {{0.f, 0.f, 0.f, 0.f}};
+        if (!REV && inb) zn = ldn<float, 4>(zet + abase + j0);
         const V Cc = ldn<float, 4>(p.C + pp);
         V un = ldn<float, 4>(p.u_next + pp), add;
 #pragma unroll
@@ -337,11 +365,17 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
                 dp = fmaf(p.dk[k], P[4 + q + k] - P[4 + q - k], dp);
                 e2 = fmaf(p.ck[k], Z[4 + q + k] + Z[4 + q - k], e2);
             }
-            const float term = REV ? e2 - dp : dp + Z[4 + q];
+            float term;
+            if (REV) {
+                term = e2 - dp;
+            } else {
+                if (inb) zn.v[q] = fmaf(B[i + q], zn.v[q], A[i + q] * (e2 + dp));
+                term = dp + zn.v[q];
+            }
             add.v[q] = Cc.v[q] * term;
             un.v[q] += add.v[q];
         }
-        (void)inb;
+        if (!REV && inb) stn<float, 4>(zet + abase + j0, zn);
         stn<float, 4>(p.u_next + pp, un);
         if (p.v) {
             V vv = ldn<float, 4>(p.v + pp);
@@ -403,7 +437,7 @@ template <typename T, int R>
 static hipError_t launch_pml_r(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
     switch (phase) {
         case 1: return launch_pml_phase<T, R, 1>(g, p, reverse, s);
-        case 2: return launch_pml_phase<T, R, 2>(g, p, reverse, s);
+        case 2: return reverse ? launch_pml_phase<T, R, 2>(g, p, reverse, s) : hipSuccess;  // forward: inside phase 3
         default: return launch_pml_phase<T, R, 3>(g, p, reverse, s);
     }
 }
