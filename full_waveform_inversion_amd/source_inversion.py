@@ -296,7 +296,7 @@ def perform_monte_carlo_sampled_waveform_inversion_sharded(real_data_array, gree
     scores the samples of its index block (the device sampler is counter-based, so the ``world``
     blocks together are exactly the samples a single GPU would draw from ``seed``), and the only
     exchange is the posterior's normaliser ``sum L`` -- ``sum_over_ranks(float) -> float``, one
-    scalar all-reduce (``dist.all_reduce`` or ``Engine.comm_allreduce_f64``).
+    scalar all-reduce (``Rendezvous.allreduce`` or ``Engine.allreduce_f64``).
 
     Returns ``(first_index, MTs_local, MTp_local, MTp_absolute_local)``; ``MTp`` is normalised over
     ALL ranks' samples (:847-848 with ``p_model = 1 / N``).
