@@ -29,13 +29,31 @@ def main(n=1500):
     d = np.einsum("kjt,j->kt", G, rng.standard_normal(6))
     marks = {}
     t0 = time.perf_counter()
+    c2 = (2000.0 + 300.0 * rng.random((40, 44))).astype(np.float32)
+    # the round-2 options take their turns too: CPML, increment form (3-D stream / 2-D fused), bf16 store, off-grid
+    # points spread on the device, the two-step 3-D kernel
+    options = [dict(), dict(abc="cpml", pml_alpha_max=20.0), dict(update_form="increment"), dict(store_dtype="bf16"),
+               dict(abc="cpml", update_form="increment")]
     for i in range(n):
-        with Engine(shape, 10.0, 1e-3, 12, npml=3, sigma_max=200.0, ckpt_interval=(4 if i % 3 == 0 else 0),
-                    image_stride=(3 if i % 3 == 1 else 1)) as e:
+        kw = options[i % len(options)]
+        plain = not kw
+        os.environ["FWI_STREAM_PAIR"] = "1" if i % 4 == 0 else "0"
+        with Engine(shape, 10.0, 1e-3, 12, npml=3, sigma_max=200.0, ckpt_interval=(4 if plain and i % 3 == 0 else 0),
+                    image_stride=(3 if plain and i % 3 == 1 else 1), **kw) as e:
             dd = e.forward(c, ([[12, 10, 14]], w), [[3, 4, 5], [20, 15, 22]], save=True)
             e.adjoint(dd)
             e.gradient()
+            e.forward(None, ([[12, 10, 14]], w), [[3, 4, 5]], save=False)
+            dp = e.forward_at(None, ([[11.3, 9.7, 13.2]], w), [[3.5, 4.25, 5.0], [20.0, 15.5, 22.75]], save=True)
+            e.misfit_l2(0.9 * dp)
+            e.adjoint(None)
             e.vec_create(2)
+        if i % 5 == 0:
+            with Engine((40, 44), 10.0, 1e-3, 12, npml=4, sigma_max=200.0,
+                        **{k: v for k, v in kw.items() if k != "store_dtype"}) as e:
+                dd = e.forward(c2, ([[20, 22]], w), [[5, 6], [30, 40]], save=True)
+                e.adjoint(dd)
+                e.gradient()
         with si.MonteCarloPlan(d, G, 512) as plan:
             plan.invert("full_mt", 300, seed=i)
         si.invert_on_device(d, G, 100, "DC", seed=i)
