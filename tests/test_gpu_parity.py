@@ -849,7 +849,7 @@ def test_random_option_combinations_fuzz(gpu, monkeypatch):
     where it applies, the two-steps-per-pass 3-D kernel for the store-free forward sweep -- forward + adjoint +
     gradient against the C oracle (the NumPy oracle's restatement for the bf16 store)."""
     rng = np.random.default_rng(4052)
-    for case in range(36):
+    for case in range(48):
         nd = int(rng.integers(2, 4))
         order = int(rng.choice([2, 4, 8]))
         shape = tuple(int(rng.integers(6, 37)) for _ in range(nd))
@@ -871,8 +871,9 @@ def test_random_option_combinations_fuzz(gpu, monkeypatch):
         bf16 = nd == 3 and form == "standard" and (abc == "sponge" or npml == 0) and rng.random() < 0.4
         ck = int(rng.choice([0, 0, 5])) if (abc == "sponge" or npml == 0) and not bf16 else 0
         pair = nd == 3 and rng.random() < 0.5
+        stride = int(rng.choice([1, 1, 3])) if ck == 0 else 1
         monkeypatch.setenv("FWI_STREAM_PAIR", "1" if pair else "0")
-        kw = dict(abc=abc, pml_alpha_max=alpha)
+        kw = dict(abc=abc, pml_alpha_max=alpha, image_stride=stride)
         if bf16:
             p = fo.Propagator(c, h, dt, order, npml, store_dtype="bf16", **kw)
         else:
@@ -887,6 +888,6 @@ def test_random_option_combinations_fuzz(gpu, monkeypatch):
             ag = e.adjoint(r)
             gg = e.gradient()
             kern = e.kernel_name
-        tag = (case, shape, order, npml, nt, abc, alpha, form, bf16, ck, pair, kern)
+        tag = (case, shape, order, npml, nt, abc, alpha, form, bf16, ck, pair, stride, kern)
         for x, ref, tol in ((d0, d, 2e-5), (dg, d, 2e-5), (ag, a, 2e-5), (gg, g, 2e-4 if bf16 else 5e-5)):
             assert np.linalg.norm(x - ref) < tol * max(np.linalg.norm(ref), 1e-300), tag
