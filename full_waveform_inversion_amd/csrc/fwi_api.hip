@@ -66,6 +66,11 @@ struct fwi_ctx {
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
+    // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
+    // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
+    void *pml_psi_fw[3] = {nullptr, nullptr, nullptr}, *pml_zeta_fw[3] = {nullptr, nullptr, nullptr};
+    void *pml_snap = nullptr;
+    size_t pml_snap_stride = 0;  // bytes of one snapshot of the memory variables
     void *pml_a[3] = {nullptr, nullptr, nullptr}, *pml_b[3] = {nullptr, nullptr, nullptr};
     size_t pml_bytes[3] = {0, 0, 0};
     void *C = nullptr;                // padded dt^2 c^2
@@ -252,6 +257,7 @@ struct Impl {
         int cur = 0;
         int prev_n = -1;
         void *v = nullptr;  // increment form: the v field of this sweep
+        bool pml_fw = false;  // CPML: this sweep is the checkpointed forward recomputation (its own memory variables)
     };
 
     static StepArgs<T> base_args(fwi_ctx *ctx, int cur) {
@@ -321,8 +327,8 @@ struct Impl {
         p.C = (const T *)ctx->C;
         p.q_out = q_out;
         for (int d = 0; d < 3; ++d) {
-            p.psi[d] = (T *)ctx->pml_psi[d];
-            p.zeta[d] = (T *)ctx->pml_zeta[d];
+            p.psi[d] = (T *)(sw.pml_fw ? ctx->pml_psi_fw[d] : ctx->pml_psi[d]);
+            p.zeta[d] = (T *)(sw.pml_fw ? ctx->pml_zeta_fw[d] : ctx->pml_zeta[d]);
             p.a[d] = (const T *)ctx->pml_a[d];
             p.b[d] = (const T *)ctx->pml_b[d];
         }
@@ -334,6 +340,23 @@ struct Impl {
         for (int k = 1; k <= ctx->gd.r; ++k) p.dk[k] = (T)(dc[k - 1] / h);
         p.npml = ctx->cfg.npml;
         return p;
+    }
+
+    // the memory variables <-> snapshot `seg` (forward set when `fw`, else the main set: the plain forward sweep)
+    static int pml_snapshot(fwi_ctx *ctx, int seg, bool fw, bool restore) {
+        char *base = (char *)ctx->pml_snap + (size_t)seg * ctx->pml_snap_stride;
+        size_t off = 0;
+        for (int d = 0; d < 3; ++d) {
+            if (!ctx->pml_psi[d]) continue;
+            for (void *arr : {fw ? ctx->pml_psi_fw[d] : ctx->pml_psi[d], fw ? ctx->pml_zeta_fw[d] : ctx->pml_zeta[d]}) {
+                if (restore)
+                    HIPCHK(ctx, hipMemcpyAsync(arr, base + off, ctx->pml_bytes[d], hipMemcpyDeviceToDevice, ctx->stream));
+                else
+                    HIPCHK(ctx, hipMemcpyAsync(base + off, arr, ctx->pml_bytes[d], hipMemcpyDeviceToDevice, ctx->stream));
+                off += ctx->pml_bytes[d];
+            }
+        }
+        return FWI_OK;
     }
 
     static int pml_zero(fwi_ctx *ctx) {
@@ -896,8 +919,16 @@ struct Impl {
             struct { void **p; size_t bytes; bool zero; } want[] = {
                 {&ctx->snap, (size_t)nseg * 2 * fb, false},
                 {&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T), false},  // K slots + carry
-                {&ctx->fwd[0], fb, false}, {&ctx->fwd[1], fb, false}, {&ctx->fwv, ctx->inc ? fb : 0, false},
-                {&ctx->fwx[0], ctx->fused2d ? fb : 0, true}, {&ctx->fwx[1], ctx->fused2d ? fb : 0, true}};
+                {&ctx->fwd[0], fb, false},
+                // (zeroed: in increment form this buffer only ever receives interior points, its halo must read 0;
+                // found by the option fuzz reusing device memory of earlier contexts)
+                {&ctx->fwd[1], fb, true}, {&ctx->fwv, ctx->inc ? fb : 0, false},
+                {&ctx->fwx[0], ctx->fused2d ? fb : 0, true}, {&ctx->fwx[1], ctx->fused2d ? fb : 0, true},
+                {&ctx->pml_psi_fw[0], ctx->pml_bytes[0], false}, {&ctx->pml_zeta_fw[0], ctx->pml_bytes[0], false},
+                {&ctx->pml_psi_fw[1], ctx->pml_bytes[1], false}, {&ctx->pml_zeta_fw[1], ctx->pml_bytes[1], false},
+                {&ctx->pml_psi_fw[2], ctx->pml_bytes[2], false}, {&ctx->pml_zeta_fw[2], ctx->pml_bytes[2], false},
+                {&ctx->pml_snap, (size_t)nseg * 2 * (ctx->pml_bytes[0] + ctx->pml_bytes[1] + ctx->pml_bytes[2]), false}};
+            ctx->pml_snap_stride = 2 * (ctx->pml_bytes[0] + ctx->pml_bytes[1] + ctx->pml_bytes[2]);
             size_t total = 0, fr = 0, tot = 0;
             for (auto &w : want) total += w.bytes;
             HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
@@ -968,6 +999,7 @@ struct Impl {
                 HIPCHK(ctx, hipMemcpyAsync(sn, sw.f[sw.cur], (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
                 HIPCHK(ctx, hipMemcpyAsync(sn + g.ptot, ctx->inc ? sw.v : sw.f[sw.cur ^ 1], (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));  // (u^n0, u^{n0-1}) or, increment form, (u^n0, v^n0)
+                if (ctx->cpml && (rc = pml_snapshot(ctx, seg, false, false))) return rc;
                 const int cnt = std::min(K, nt - n0);
                 if (fused)
                     rc = run_fused(ctx, sw, spare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, &ctx->rec, series,
@@ -1115,6 +1147,8 @@ struct Impl {
                 fw.f[0] = ctx->fwd[0];
                 fw.f[1] = ctx->fwd[1];
                 fw.v = ctx->fwv;
+                fw.pml_fw = true;
+                if (ctx->cpml && (rc = pml_snapshot(ctx, seg, true, true))) return rc;
                 auto qo = [&](int n) -> T * { return q_store + (size_t)(n - n0) * g.npts; };
                 if ((rc = run_steps(ctx, fw, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr, T(0), qo,
                                     noq)))
@@ -1403,8 +1437,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         (cfg->ndim != 3 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
          cfg->update_form != FWI_UPDATE_STANDARD || (cfg->abc == FWI_ABC_CPML && cfg->npml > 0)))
         return bad("store_dtype bf16: 3-D fp32 stream kernel, standard update form, sponge border, no checkpointing");
-    if (cfg->abc == FWI_ABC_CPML && cfg->npml > 0 && cfg->ckpt_interval > 0)
-        return bad("abc cpml and ckpt_interval > 0 cannot be combined (the snapshots do not hold the memory variables)");
+
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         g_create_error = "fwi_create: no HIP device available (this library has no CPU fallback)";
@@ -1512,8 +1545,10 @@ void fwi_destroy(fwi_ctx *ctx) {
     for (void *v : ctx->vecs)
         if (v) (void)hipFree(v);
     for (int d = 0; d < 3; ++d)
-        for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d]})
+        for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d], ctx->pml_psi_fw[d],
+                        ctx->pml_zeta_fw[d]})
             if (q) (void)hipFree(q);
+    if (ctx->pml_snap) (void)hipFree(ctx->pml_snap);
     for (fwi_ctx::SpreadSet *sp : {&ctx->src_sp, &ctx->rec_sp})
         for (void *q : {sp->pt_start, sp->owner, sp->weight})
             if (q) (void)hipFree(q);

@@ -25,6 +25,9 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((22, 9, 30), 2, 5, 20.0, "float64", TOL64, "step3d_stream", {}),     # ny < 2 npml: the y borders overlap
     ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {"update_form": "increment"}),
     ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step_point", {"kernel": "point"}),
+    ((40, 36, 44), 8, 6, 30.0, "float32", TOL32, "step3d_stream", {"ckpt_interval": 16}),  # snapshots hold psi, zeta
+    ((40, 36, 44), 8, 6, 30.0, "float64", TOL64, "step3d_stream", {"ckpt_interval": 7, "update_form": "standard"}),
+    ((70, 90), 8, 8, 40.0, "float32", TOL32, "step2d_tile", {"ckpt_interval": 10}),
     ((70, 90), 8, 8, 40.0, "float32", TOL32, "step2d_tile", {}),          # 2-D: one step per launch with the CPML
     ((70, 91), 2, 7, 0.0, "float32", TOL32, "step2d_tile", {}),
     ((70, 90), 8, 8, 40.0, "float64", TOL64, "step_point", {}),
@@ -95,7 +98,7 @@ def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
 
 def test_cpml_configuration_errors(gpu):
     with pytest.raises(FwiError) as ei:
-        Engine((32, 32), 10.0, 1e-3, 8, npml=4, sigma_max=100.0, abc="cpml", ckpt_interval=4)
+        Engine((32, 32, 32), 10.0, 1e-3, 8, npml=4, sigma_max=100.0, abc="cpml", store_dtype="bf16")
     assert ei.value.code == 1
     with pytest.raises(FwiError):
         Engine((32, 32), 10.0, 1e-3, 8, npml=4, sigma_max=100.0, abc="cpml", pml_alpha_max=-1.0)
