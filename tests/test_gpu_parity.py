@@ -776,6 +776,70 @@ def test_store_too_large_is_a_clean_error(gpu):
         assert d.shape == (4, 1)
 
 
+def test_1024_cubed_grid_addressing_by_translation(gpu):
+    """The largest grid the tests run: 1024^3 (4 GiB per field, element indices past 2^30, byte offsets past 2^32, a
+    forward-term store of 26 GB whose slot offsets pass 2^32 elements).  No oracle finishes that in seconds, so the
+    check is the translation property: a shot in the far corner of the big grid, inside a block of heterogeneous
+    model, must give the seismograms, adjoint traces and gradient of the same shot in a 96^3 grid that holds just that
+    block -- the wave cannot reach the small grid's near faces within ``nt`` steps (4 cells per step), and the far
+    faces (with their absorbing border) coincide."""
+    N, n, nt, npml = 1024, 96, 6, 8
+    o = N - n
+    rng = np.random.default_rng(7)
+    blk = (2000.0 + 600.0 * rng.random((n, n, n))).astype(np.float32)
+    src = np.array([[50, 48, 52], [70, 60, 44]], np.int32)
+    rec = np.array([[46, 52, 49], [60, 55, 58], [80, 70, 66], [90, 88, 91]], np.int32)
+    wav = rng.standard_normal((nt, 2)).astype(np.float32)
+    res = rng.standard_normal((nt, 4)).astype(np.float32)
+    with Engine((n, n, n), 10.0, 1e-3, nt, npml=npml, sigma_max=300.0) as e:
+        d_s = e.forward(blk, (src, wav), rec, save=True)
+        a_s = e.adjoint(res)
+        g_s = e.gradient("slowness2")
+    big = np.full((N, N, N), 2000.0, np.float32)
+    big[o:, o:, o:] = blk
+    with Engine((N, N, N), 10.0, 1e-3, nt, npml=npml, sigma_max=300.0) as e:
+        d_b = e.forward(big, (src + o, wav), rec + o, save=True)
+        a_b = e.adjoint(res)
+        g_b = e.gradient("slowness2")
+    del big
+    assert np.all(np.isfinite(d_b)) and np.linalg.norm(d_s) > 0 and np.linalg.norm(g_s) > 0
+    assert rel(d_b, d_s) < 1e-6 and rel(a_b, a_s) < 1e-6
+    assert rel(g_b[o:, o:, o:], g_s) < 1e-6
+    outside = g_b.copy()
+    outside[o:, o:, o:] = 0.0
+    assert not outside.any()  # nothing was written anywhere else in the 4 GiB image
+
+
+@pytest.mark.parametrize("nt", [8, 10])
+def test_16384_squared_grid_addressing_by_translation(gpu, nt):
+    """The same property in 2-D at 16384^2 (1 GiB per field, ~80 k tiles of the fused kernel, the XCD-contiguous tile
+    walk at that count); ``nt`` = two fused launches, and two plus a two-step tail."""
+    N, n, npml = 16384, 160, 8
+    o = N - n
+    rng = np.random.default_rng(11)
+    blk = (2000.0 + 600.0 * rng.random((n, n))).astype(np.float32)
+    src = np.array([[80, 84], [100, 70]], np.int32)
+    rec = np.array([[78, 88], [90, 95], [120, 110], [150, 152]], np.int32)
+    wav = rng.standard_normal((nt, 2)).astype(np.float32)
+    res = rng.standard_normal((nt, 4)).astype(np.float32)
+    out = []
+    for shape, model, off in (((n, n), blk, 0), ((N, N), None, o)):
+        if model is None:
+            model = np.full((N, N), 2000.0, np.float32)
+            model[o:, o:] = blk
+        with Engine(shape, 10.0, 1e-3, nt, npml=npml, sigma_max=300.0) as e:
+            d = e.forward(model, (src + off, wav), rec + off, save=True)
+            a = e.adjoint(res)
+            g = e.gradient("slowness2")
+            out.append((d, a, g, e.kernel_name))
+    (d_s, a_s, g_s, _), (d_b, a_b, g_b, kern) = out
+    assert kern == "step2d_fused"
+    assert np.linalg.norm(d_s) > 0 and np.linalg.norm(g_s) > 0
+    assert rel(d_b, d_s) < 1e-6 and rel(a_b, a_s) < 1e-6 and rel(g_b[o:, o:], g_s) < 1e-6
+    g_b[o:, o:] = 0.0
+    assert not g_b.any()
+
+
 def test_engine_pool_on_gpu_matches_single_engine(gpu):
     """2-D shots overlapped on one GPU (three contexts, three host threads) == one after the other."""
     from full_waveform_inversion_amd import shots as sh
