@@ -131,6 +131,26 @@ def test_no_torch_on_the_product_and_bench_path():
         assert not re.search(r"^\s*(import|from)\s+torch\b", open(f).read(), re.M), f
 
 
+def test_the_package_never_reaches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import it, in source or at run time (bench.py
+    does, for its cpu_baseline leg only)."""
+    import re
+    import subprocess
+    import sys
+    for dirpath, _, fs in os.walk(os.path.join(ROOT, "full_waveform_inversion_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
+    code = ("import sys, importlib, full_waveform_inversion_amd as p\n"
+            "import os\n"
+            "[importlib.import_module(p.__name__ + '.' + f[:-3]) for f in sorted(os.listdir(p.__path__[0]))"
+            " if f.endswith('.py') and f != '__init__.py']\n"
+            "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.') or m == 'torch']\n"
+            "assert not bad, bad\n")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
 def test_shot_parallel_world2_matches_serial(tmp_path):
     """Two processes, 5 shots split 3 + 2, gradient and misfit summed over the control plane == serial."""
     out = str(tmp_path / "res")
