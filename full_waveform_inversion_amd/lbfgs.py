@@ -13,7 +13,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
           gtol=0.0, callback=None, c2=0.9):
     """Minimise ``f`` given ``fg(x) -> (f, g)``.
 
-    Line search: backtracking until the Armijo condition holds; while no backtracking was needed and the slope
+    Line search: backtracking (safeguarded quadratic interpolation) until the Armijo condition holds; while no backtracking was needed and the slope
     along the direction is still steeper than ``c2`` times the initial one (the weak Wolfe curvature condition
     fails: the step is too short, typical of the first, hand-scaled iteration) the step is doubled instead, as
     long as the misfit keeps decreasing.  ``c2=None`` switches the expansion off (plain Armijo).
@@ -72,7 +72,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
             elif best is not None:
                 break      # the doubled step overshot: keep the last good one
             else:
-                t *= 0.5
+                t = _backtrack(t, f, gp, fn)
                 shrunk = True
         if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
@@ -91,6 +91,15 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         if callback:
             callback(it, x, f, g)
     return x, f, log
+
+
+def _backtrack(t, f0, gp, ft):
+    """Next trial step after ``t`` failed the Armijo test: the minimiser of the parabola through ``f(0) = f0``,
+    ``f'(0) = gp`` and ``f(t) = ft``, kept inside ``[t / 10, t / 2]`` (a misfit evaluation is a full sweep over
+    the shots, so a badly scaled first step should cost two or three of them, not one per halving)."""
+    curv = ft - f0 - gp * t
+    tq = -gp * t * t / (2.0 * curv) if np.isfinite(curv) and curv > 0.0 else 0.5 * t
+    return min(max(tq, 0.1 * t), 0.5 * t)
 
 
 def _require_finite(f, gmax, gg, it):
@@ -171,7 +180,7 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
             elif best is not None:
                 break
             else:
-                t *= 0.5
+                t = _backtrack(t, f, gp, fn)
                 shrunk = True
         if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})

@@ -209,6 +209,20 @@ def test_lbfgs_quadratic_and_rosenbrock():
     assert f < 1e-8 and np.allclose(x, 1.0, atol=1e-3)
 
 
+def test_lbfgs_recovers_from_a_far_too_long_first_step_in_few_evaluations():
+    """A first step 100x too long: interpolating the parabola through f(0), f'(0) and the failed trial finds the
+    scale in two or three misfit evaluations (each one a sweep over all shots) where halving needs seven."""
+    rng = np.random.default_rng(3)
+    A = np.diag(1.0 + 4.0 * rng.random(30))
+    b = rng.standard_normal(30)
+    g0 = np.abs(b).max()
+    exact = g0 * (b @ b) / (b @ A @ b)      # first_step that lands on the minimiser along -g
+    x, f, log = lbfgs(lambda x: (0.5 * x @ A @ x - b @ x, A @ x - b), np.zeros(30), maxiter=3, history=4,
+                      first_step=100.0 * exact)
+    assert log[1]["evals"] - log[0]["evals"] <= 3 and log[1]["f"] < log[0]["f"]
+    assert 0.2 / 100.0 < log[1]["step"] < 2.0 / 100.0
+
+
 def test_lbfgs_expands_a_too_short_first_step():
     """The first step of an FWI run is scaled by hand (`first_step`); when it is far too short the slope along
     the direction is still steep at the trial point (weak Wolfe curvature fails) and the search doubles the step

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--npml", type=int, default=-1, help="override the workload's border width")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"])
@@ -25,6 +26,8 @@ def main():
     w = workloads.CONFIGS[a.config](a.scale)
     if a.nt:
         w.nt = a.nt
+    if a.npml >= 0:
+        w.npml = a.npml
     wav = w.wavelet(np.dtype(a.dtype).type)
     src = w.src_idx[:1]
     e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, kernel=a.kernel, dtype=a.dtype, abc=a.abc,
