@@ -191,7 +191,10 @@ def main():
     from full_waveform_inversion_amd.rendezvous import Rendezvous
     from full_waveform_inversion_amd.shots import RcclExchange
 
-    rdzv = Rendezvous.from_env(timeout=float(os.environ.get("FWI_RDZV_TIMEOUT", "300"))) if world > 1 else None
+    # FWI_BENCH_FORCE_EXCHANGE=1: take the N > 1 code path (rendezvous, RCCL communicator, timed all-reduce, max over
+    # ranks) even with one rank -- how the one-GPU test box rehearses exactly what the driver launches for N = 2, 4, 8
+    multi = world > 1 or os.environ.get("FWI_BENCH_FORCE_EXCHANGE") == "1"
+    rdzv = Rendezvous.from_env(timeout=float(os.environ.get("FWI_RDZV_TIMEOUT", "300"))) if multi else None
 
     def exchange(e):
         # a communicator that neither comes up nor fails must not hang the job: hard exit with a traceback
@@ -217,8 +220,8 @@ def main():
         w, el, kern_us, info = run_leg(
             headline_workload, local, args.steps, args.warmup, grad=grad,
             engine_kw=dict(kernel=args.kernel, zchunk=args.zchunk, image_stride=S),
-            exchange=exchange if world > 1 else None, barrier=rdzv.barrier if rdzv else None,
-            max_over_ranks=max_over_ranks if world > 1 else None)
+            exchange=exchange if multi else None, barrier=rdzv.barrier if rdzv else None,
+            max_over_ranks=max_over_ranks if multi else None)
         if rank == 0:
             npts = int(np.prod(w.shape))
             sweeps = 2 if grad else 1            # forward + adjoint sweep per shot
@@ -240,7 +243,7 @@ def main():
                                        "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
                            "kernel": info["kernel"], "image_stride": S,
                            "parallelism": "shot-parallel x%d" % world,
-                           "exchange": "none" if world == 1 else
+                           "exchange": "none" if not multi else
                                        "one rccl allreduce of the gradient accumulator after the K shots (timed)",
                            "rccl_ranks": info["rccl_ranks"], "control_plane": "stdlib tcp rendezvous (no torch)"},
                 "roofline": roofline_entry(

@@ -47,3 +47,24 @@ def test_more_ranks_than_launched_is_an_error_not_a_silent_single_gpu_run(gpu):
                        stderr=subprocess.PIPE, timeout=120, env={k: v for k, v in os.environ.items()
                                                                   if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert p.returncode != 0 and b"torch.distributed.run" in p.stderr
+
+
+def test_the_multi_rank_path_as_the_driver_launches_it_with_one_rank(gpu):
+    """`python -m torch.distributed.run --nproc-per-node 1 ... bench.py` with FWI_BENCH_FORCE_EXCHANGE=1: the launcher,
+    the stdlib rendezvous on MASTER_PORT + 1.., ncclCommInitRank, the warm-up and the timed all-reduce of the gradient
+    accumulator and the max-over-ranks reduction all run -- everything of the N = 2, 4, 8 runs except a second GPU."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, FWI_BENCH_FORCE_EXCHANGE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--leg", "headline", "--grid", "64", "--nt", "40", "--steps", "2", "--warmup",
+                        "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and "rccl allreduce" in d["config"]["exchange"]
+    assert d["value"] > 0
