@@ -15,7 +15,9 @@
 #include "fwi_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace fwi {
@@ -675,18 +677,60 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
     // 2-D: rows per workgroup.  16 is 7 % faster for a lone shot (6.98 vs 7.46 us/step at 1024^2) but
     // 8 co-schedules better when several shots share the GPU (4 concurrent: 3.5 vs 4.4 us/step/shot).
     if (g.ndim == 2) return StreamTuning{8, 1, 1, tile_x};
-    // Measured on MI355X (tools/tune_stream.py): fastest is ONE resident round of workgroups
-    // (about one per CU, 256 CUs) each marching as many planes as possible, because every
-    // z-chunk re-reads 2r halo planes and pays a 2r-plane prologue.  256^3: TY 4 x zchunk 64
-    // (256 workgroups) 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256 328 vs TY 4 x 256 302
-    // (8 rows per tile halve the y-halo re-read once the z chunks are long anyway).
-    StreamTuning best{4, g.nz, 1, tile_x};
+    // Measured on MI355X (tools/tune_stream.py, tools/size_sweep.py; profiles/r02_stream_tuning_sweep.txt).  Two
+    // things decide: every z chunk re-reads 2r halo planes and pays a prologue (~10 planes' worth), so chunks should
+    // be long; and workgroups run in rounds of one per CU (256), so the last round should not be a sliver -- a grid
+    // whose tiles make 288 columns (768^3 with 8-row tiles) spends its second round on 32 workgroups (235 Gpts/s;
+    // 305 with 96-plane chunks = 9 full rounds).  Cost of a candidate (rows per tile, chunks), relative to ideal,
+    // with W = the workgroups that saturate the memory system:
+    //   (1 + 10 / zchunk) x sum over rounds of max(1, workgroups in the round / W), over (workgroups / W)
+    // Two regimes: while the three fields fit the Infinity Cache every CU counts (W = 256) and 4-row tiles cost
+    // nothing extra -- their third read of a y row hits in L2; from HBM ~200 workgroups already saturate (W = 200;
+    // 384^3 is fastest with 192 workgroups of 192 planes, not with 768 of 48) and the 4-row tile's extra row reads
+    // show (200 x 400 x 400: TY 8 x 100 planes 283 Gpts/s, TY 4 x 200 planes 240).  The model reproduces the
+    // hand-tuned choices of round 1 (256^3: TY 4 x 64 planes, 407 Gpts/s vs TY 8 x 32 347; 512^3: TY 8 x 256, 328 vs
+    // TY 4 x 256 302) and the measured ranking of the chunk lengths at 300^3, 384^3 and 768^3; against the round-1
+    // rule (one round, then stop; FWI_STREAM_TUNING=legacy) it changes 700^3 (+39 %) and 768^3 (+24 %) and nothing
+    // else from 96^3 to 1024^3.  What it cannot fix: a grid whose columns make 192 - 240 workgroups runs at about
+    // that share of the 512^3 rate (384^3: 280 vs 352 Gpts/s) -- per-CU throughput is bounded (neither a deeper
+    // prefetch, PF = 2, nor fuller waves, 32-lane rows for 100 % lane use at 384^3, moved it: both measured, both
+    // dropped), and shorter chunks to fill more rounds cost more in halo planes than the idle CUs do.
+    static const bool legacy = getenv("FWI_STREAM_TUNING") && !strcmp(getenv("FWI_STREAM_TUNING"), "legacy");
+    if (legacy) {
+        StreamTuning best{4, g.nz, 1, tile_x};
+        for (int ty : {8, 4}) {
+            const int64_t tiles_xy = stream_nxt(g, tile_x) * (round_up(g.ny, ty) / ty);
+            const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
+            const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
+            best = StreamTuning{ty, zc, 1, tile_x};
+            if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
+        }
+        return best;
+    }
+    constexpr double CUS = 256.0, PROLOGUE = 10.0;
+    // (200 MiB: 256^3 = 192 MiB is resident, 272^3 = 230 MiB measurably is not -- it runs 12 % faster tuned as HBM)
+    const bool cache_resident = 3.0 * (double)g.npts * (is_f32 ? 4 : 8) <= 200.0 * 1024 * 1024;
+    const double WSAT = cache_resident ? 256.0 : 200.0, TY4_PENALTY = cache_resident ? 1.0 : 1.15;
+    StreamTuning best{8, g.nz, 1, tile_x};
+    double best_cost = 1e30;
+    const int zc_min = std::min(g.nz, 16);
     for (int ty : {8, 4}) {
         const int64_t tiles_xy = stream_nxt(g, tile_x) * (round_up(g.ny, ty) / ty);
-        const int nzc = (int)std::max<int64_t>(1, std::min<int64_t>(g.nz, 256 / std::max<int64_t>(1, tiles_xy)));
-        const int zc = std::max((g.nz + nzc - 1) / nzc, std::min(g.nz, 16));
-        best = StreamTuning{ty, zc, 1, tile_x};
-        if (zc >= 64 || zc >= g.nz) break;  // long enough chunks with 8-row tiles: keep them
+        int last_zc = 0;
+        for (int nzc = 1; nzc <= g.nz; ++nzc) {
+            const int zc = (g.nz + nzc - 1) / nzc;
+            if (zc < zc_min) break;
+            if (zc == last_zc) continue;
+            last_zc = zc;
+            const double nblk = (double)tiles_xy * ((g.nz + zc - 1) / zc);
+            const double full = std::floor(nblk / CUS), rem = nblk - full * CUS;
+            const double rounds = full * (CUS / WSAT) + (rem > 0 ? std::max(1.0, rem / WSAT) : 0.0);
+            const double cost = (1.0 + PROLOGUE / zc) * rounds / (nblk / WSAT) * (ty == 4 ? TY4_PENALTY : 1.0);
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best = StreamTuning{ty, zc, 1, tile_x};
+            }
+        }
     }
     return best;
 }
