@@ -140,6 +140,14 @@ class Rendezvous:
         raise RendezvousError("rank %d found no rank 0 on %s:%d..%d within %.0f s"
                               % (self.rank, self.addr, self.port + 1, self.port + _PORT_SPAN, self.timeout))
 
+    def set_timeout(self, seconds):
+        """Bound how long a collective waits for a peer from now on (an optional phase of a job can then fail
+        in seconds instead of holding the other ranks for the set-up timeout)."""
+        self.timeout = float(seconds)
+        for s in self._peers + [self._up]:
+            if s is not None:
+                s.settimeout(self.timeout)
+
     def close(self):
         for s in self._peers + [self._up, self._listener]:
             if s is not None:

@@ -57,14 +57,18 @@ def test_the_multi_rank_path_as_the_driver_launches_it_with_one_rank(gpu):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    env = dict(os.environ, FWI_BENCH_FORCE_EXCHANGE="1")
+    env = dict(os.environ, FWI_BENCH_FORCE_EXCHANGE="1", FWI_BENCH_FORCE_2D_SCALING="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "1", "--leg", "headline", "--grid", "64", "--nt", "40", "--steps", "2", "--warmup",
-                        "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+                        "1", "--leg-nt", "200"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and "rccl allreduce" in d["config"]["exchange"]
     assert d["value"] > 0
+    # the 2-D configuration rides along in N > 1 runs (control-plane barriers only); optional, so errors are recorded
+    leg = d["legs"]["cfg2"]
+    assert "error" not in leg, leg
+    assert leg["n_gpus"] == 1 and leg["kernel"] == "step2d_fused" and leg["Gpts_per_s"] > 50

@@ -121,6 +121,38 @@ def test_control_plane_skips_a_foreign_listener_and_times_out_alone():
         Rendezvous(2, 2)
 
 
+def test_control_plane_bounded_wait_for_an_optional_phase():
+    """`set_timeout`: after set-up a collective gives up on a silent peer within the new bound (bench.py's optional
+    2-D scaling leg must never hold the ranks for the set-up timeout), and on a peer that has gone at once."""
+    import socket
+    import threading
+    import time
+    from full_waveform_inversion_amd.rendezvous import Rendezvous, RendezvousError
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    box = {}
+
+    def peer():
+        box["r1"] = Rendezvous(1, 2, "127.0.0.1", port, timeout=20.0)
+        box["r1"].barrier()          # takes part in the first barrier, then stays silent
+
+    t = threading.Thread(target=peer)
+    t.start()
+    r0 = Rendezvous(0, 2, "127.0.0.1", port, timeout=20.0)
+    r0.barrier()
+    t.join()
+    r0.set_timeout(0.5)
+    t0 = time.monotonic()
+    with pytest.raises((RendezvousError, OSError)):
+        r0.barrier()
+    assert time.monotonic() - t0 < 5.0
+    box["r1"].close()
+    with pytest.raises((RendezvousError, OSError)):
+        r0.allreduce([1.0])
+    r0.close()
+
+
 def test_no_torch_on_the_product_and_bench_path():
     """north_star: "host code stays in Python calling HIP through a thin ctypes C-ABI shim (no PyTorch)"."""
     import re
