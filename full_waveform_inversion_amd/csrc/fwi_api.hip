@@ -63,6 +63,7 @@ struct fwi_ctx {
     size_t qes = 4;      // bytes per stored forward-term element
     bool pair3d = false;
     int pair_zc = 0, pair_tw = 256;
+    int fused_skipd = -1;  // Fused2dArgs::skipd (FWI_FUSED2D_SKIPD, read at create)
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
@@ -749,6 +750,7 @@ struct Impl {
                 a.u_cur = (const float *)sw.f[sw.cur];
                 a.u_prev = (const float *)(ctx->inc ? sw.v : sw.f[sw.cur ^ 1]);  // increment form: v in / v out
                 a.inc = ctx->inc ? 1 : 0;
+                a.skipd = ctx->fused_skipd;
                 a.C = (const float *)ctx->C;
                 a.out_cur = (float *)spare[0];
                 a.out_prev = (float *)spare[1];
@@ -1490,6 +1492,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // (the CPML's slab kernels run between time steps: one step per launch, the tile kernel)
     // Increment form in 2-D: the fused kernel carries it (same traffic as the standard form); the steps it cannot take
     // (step counts off the multiple of 4) go through the point kernel, which ctx->kernel names in that case.
+    if (const char *sk = getenv("FWI_FUSED2D_SKIPD")) ctx->fused_skipd = atoi(sk) != 0;  // tuning / test hook
     ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && !ctx->cpml && !getenv("FWI_NO_FUSED2D") &&
                    (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /

@@ -70,7 +70,8 @@ __device__ unsigned long long fwi_fused2d_stamps[4096 * 8];
 // INC: increment form (fwi_config.update_form): the second field is v = u - u_prev instead of u_prev; v' = A (B v + q),
 // u' = u + v'.  The tile then holds u twice (ping-pong: u' cannot overwrite u while neighbours still read it), v and C
 // = four LDS images (148 KB); HBM traffic is the same as in the standard form (u, v, C in; u, v out).
-template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE, bool INC>
+// SKIPD: grids of more than one round of tiles (> 256) -- see the note at the damping profiles below.
+template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE, bool INC, bool SKIPD = false>
 __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
     constexpr int FNT = 1024;  // all modes fit the 128-VGPR cap of 1024 threads (68 - 102 VGPRs, no scratch)
     constexpr int HL = (KS * R + 3) / 4 * 4;  // halo cells per side (float4 aligned)
@@ -136,11 +137,21 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
             }
         }
     }
+    // Most tiles of a large grid lie wholly inside the absorbing border's inner edge: their damping is identically
+    // zero, and the damped update (two more multiplies, a reciprocal and its Newton step per cell: ~40 % of a
+    // sub-step's arithmetic) reduces to the plain one.  Workgroup-uniform, decided from the profiles just loaded.
+    // Only where it pays (SKIPD): a grid of one round of tiles (1024^2 = 256 tiles = 256 CUs) ends with its slowest,
+    // i.e. border, workgroups whatever the interior ones save, and the branch costs those 3.5 % (10.9 -> 11.3 us
+    // per launch); from two rounds on the interior tiles' saving is the launch's: 2048^2 417 -> 442, 3000^2 425 ->
+    // 459, 8192^2 426 -> 444 Gpts/s.
+    int any_damping = 0;
     if (DAMP) {
         for (int i = tid; i < E; i += FNT) {
             const int z = z0 + i, x = x0 + i;
-            dzs[i] = (z >= 0 && z < g.nz) ? a.dz[z] : 0.f;
-            dxs4[i >> 2].v[i & 3] = (x >= 0 && x < g.nx) ? a.dx[x] : 0.f;
+            const float dzv = (z >= 0 && z < g.nz) ? a.dz[z] : 0.f, dxv = (x >= 0 && x < g.nx) ? a.dx[x] : 0.f;
+            dzs[i] = dzv;
+            dxs4[i >> 2].v[i & 3] = dxv;
+            any_damping |= (dzv != 0.f) | (dxv != 0.f);
         }
     }
     // fixed map of the interior (imaging accumulators, q prefetch, final stores): group ii = tid + i FNT
@@ -149,7 +160,11 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
 #pragma unroll
         for (int i = 0; i < IPT; ++i) gacc[i] = {{0.f, 0.f, 0.f, 0.f}};
     }
-    __syncthreads();
+    bool damped = DAMP;
+    if (DAMP && SKIPD)
+        damped = __syncthreads_or(any_damping) != 0;  // (the barrier that ends the fill)
+    else
+        __syncthreads();
     FWI_STAMP(1);
 
     q4(*cur)[E4] = fa;
@@ -209,24 +224,34 @@ __global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) 
                 }
             }
             const q4 up = INC ? fv[INC ? lz : 0][l4] : prv[lz][l4], Cc = fc[lz][l4];
-            q4 q, un, vn, dxv;
-            if (DAMP) dxv = dxs4[l4];
+            // (q = C L u is formed inside either branch, next to the sum it feeds: hipcc then contracts multiply and
+            // add the same way as in step2d_tile, and the kernels stay bit-identical -- runs whose step count is not
+            // a multiple of 4 mix them, and a checkpointed run recomputes with the one what the other stored)
+            q4 q, un, vn;
+            if (DAMP && (!SKIPD || damped)) {
+                const q4 dxv = dxs4[l4];
+                const float dzv = dzs[lz];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                q.v[j] = Cc.v[j] * lap.v[j];
-                if (INC) {
-                    if (DAMP) {
-                        const float d = dzs[lz] + dxv.v[j];
+                for (int j = 0; j < 4; ++j) {
+                    q.v[j] = Cc.v[j] * lap.v[j];
+                    const float d = dzv + dxv.v[j];
+                    if (INC) {
                         vn.v[j] = fmaf(1.f - d, up.v[j], q.v[j]) * rcp1(1.f + d);
+                        un.v[j] = c.v[j] + vn.v[j];
                     } else {
-                        vn.v[j] = up.v[j] + q.v[j];
+                        un.v[j] = (fmaf(2.f, c.v[j], -(1.f - d) * up.v[j]) + q.v[j]) * rcp1(1.f + d);
                     }
-                    un.v[j] = c.v[j] + vn.v[j];
-                } else if (DAMP) {
-                    const float d = dzs[lz] + dxv.v[j];
-                    un.v[j] = (fmaf(2.f, c.v[j], -(1.f - d) * up.v[j]) + q.v[j]) * rcp1(1.f + d);
-                } else {
-                    un.v[j] = (2.f * c.v[j] - up.v[j]) + q.v[j];
+                }
+            } else {  // d = 0: the same expressions with B = A = 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q.v[j] = Cc.v[j] * lap.v[j];
+                    if (INC) {
+                        vn.v[j] = up.v[j] + q.v[j];
+                        un.v[j] = c.v[j] + vn.v[j];
+                    } else {
+                        un.v[j] = (2.f * c.v[j] - up.v[j]) + q.v[j];
+                    }
                 }
             }
             if (INC) fv[INC ? lz : 0][l4] = vn;  // in place: only this thread touches v here
@@ -334,33 +359,41 @@ int fused2d_num_tiles(const GridDesc &g) {
     return ((g.nx + FUSED2D_TILE - 1) / FUSED2D_TILE) * ((g.nz + FUSED2D_TILE - 1) / FUSED2D_TILE);
 }
 
-template <int R, bool DAMP>
+template <int R, bool DAMP, bool SKIPD>
 static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
     constexpr int KS = FUSED2D_STEPS, FT = FUSED2D_TILE;
     const dim3 grid(fused2d_num_tiles(g));
     if (a.inc) {
         if (a.mode == 1)
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, true>), grid, dim3(1024), 0, s, a, g);
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
         else if (a.mode == 2)
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, true>), grid, dim3(1024), 0, s, a, g);
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
         else
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, true>), grid, dim3(1024), 0, s, a, g);
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
     } else if (a.mode == 1)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, false>), grid, dim3(1024), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
     else if (a.mode == 2)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, false>), grid, dim3(1024), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
     else
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, false>), grid, dim3(1024), 0, s, a, g);
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
     return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_fused_d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
+    if (!a.damp) return launch_fused_r<R, false, false>(g, a, s);
+    // more than one round of workgroups: interior tiles skip the damped update (FWI_FUSED2D_SKIPD=0 / 1 forces)
+    const bool skip = a.skipd >= 0 ? a.skipd != 0 : fused2d_num_tiles(g) > 256;
+    return skip ? launch_fused_r<R, true, true>(g, a, s) : launch_fused_r<R, true, false>(g, a, s);
 }
 
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a0, hipStream_t s) {
     static const bool no_remap = getenv("FWI_FUSED2D_NOREMAP") != nullptr;  // tuning hook
     Fused2dArgs a = a0;
     a.xcd_remap = no_remap ? 0 : 1;
-    if (g.r == 4) return a.damp ? launch_fused_r<4, true>(g, a, s) : launch_fused_r<4, false>(g, a, s);
-    if (g.r == 2) return a.damp ? launch_fused_r<2, true>(g, a, s) : launch_fused_r<2, false>(g, a, s);
-    return a.damp ? launch_fused_r<1, true>(g, a, s) : launch_fused_r<1, false>(g, a, s);
+    if (g.r == 4) return launch_fused_d<4>(g, a, s);
+    if (g.r == 2) return launch_fused_d<2>(g, a, s);
+    return launch_fused_d<1>(g, a, s);
 }
 
 }  // namespace fwi

@@ -168,6 +168,7 @@ struct Fused2dArgs {
     int n0, dn;                        // first step index of the launch and +1 / -1
     int xcd_remap;                     // set by launch_fused2d: XCD-contiguous tile numbering
     int inc;                           // increment form: u_prev / out_prev are the v field in / out
+    int skipd;                         // interior tiles skip the damped update: -1 = by tile count, 0 / 1 = forced
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
     const int *inj_start, *inj_lz, *inj_lx, *inj_col;
     const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)

@@ -615,6 +615,35 @@ def test_2d_kernels_agree(gpu, monkeypatch):
         assert rel(out[k]["grad_c"], out["point"]["grad_c"]) < 1e-5
 
 
+def test_2d_fused_and_tile_kernels_are_bit_identical_with_interior_tiles(gpu, monkeypatch):
+    """A 5 x 5-tile grid: the fused kernel's interior tiles (no damping anywhere in their extended region) take the
+    plain update, the border tiles the damped one; both must give the bits of `step2d_tile` -- step counts off the
+    multiple of 4 and checkpointed runs mix the two kernels within one shot."""
+    rng = np.random.default_rng(8)
+    shape = (300, 290)
+    c = (1500.0 + 1500.0 * rng.random(shape)).astype(np.float32)
+    dt = 0.7 * fo.cfl_dt(float(c.max()), 5.0, 2, 8)
+    nt = 64
+    src = np.array([[150, 140], [20, 30], [128, 192]])
+    rec = np.stack([rng.integers(0, s, 40) for s in shape], 1)
+    wav = rng.standard_normal((nt, 3)).astype(np.float32)
+    out = {}
+    monkeypatch.setenv("FWI_FUSED2D_SKIPD", "1")  # (by itself the variant is taken from 257 tiles on)
+    for name, nofuse in (("tile", "1"), ("fused", None)):
+        if nofuse:
+            monkeypatch.setenv("FWI_NO_FUSED2D", nofuse)
+        else:
+            monkeypatch.delenv("FWI_NO_FUSED2D", raising=False)
+        for form in ("standard", "increment"):
+            with Engine(shape, 5.0, dt, nt, order=8, npml=10, sigma_max=900.0, update_form=form,
+                        kernel=("auto" if form == "increment" else "stream")) as e:
+                d = e.forward(c, (src, wav), rec, save=False)
+                out[name, form] = (d, e.kernel_name)
+    assert out["tile", "standard"][1] == "step2d_tile" and out["fused", "standard"][1] == "step2d_fused"
+    assert np.array_equal(out["fused", "standard"][0], out["tile", "standard"][0])
+    assert rel(out["fused", "increment"][0], out["tile", "increment"][0]) < 2e-6  # (point kernel: another summation order)
+
+
 @pytest.mark.parametrize("shape,K", [((40, 36, 44), 7), ((40, 36, 44), 1), ((40, 36, 44), 500), ((96, 100), 16),
                                      ((96, 100), 7), ((96, 100), 8)])
 def test_checkpointed_gradient_equals_store_all(gpu, shape, K):
