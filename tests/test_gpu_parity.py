@@ -870,11 +870,13 @@ def test_16384_squared_grid_addressing_by_translation(gpu, nt):
     assert not g_b.any()
 
 
-def test_engine_pool_on_gpu_matches_single_engine(gpu):
-    """2-D shots overlapped on one GPU (three contexts, three host threads) == one after the other."""
+@pytest.mark.parametrize("maker", ["cfg3", "cfg5"])
+def test_engine_pool_on_gpu_matches_single_engine(gpu, maker):
+    """Shots overlapped on one GPU (three contexts, three host threads) == one after the other; 2-D (where the pool is
+    the default) and 3-D (a pool of one by default, but nothing may depend on that)."""
     from full_waveform_inversion_amd import shots as sh
 
-    w = workloads.cfg3(0.125, nshots=6)
+    w = workloads.cfg3(0.125, nshots=6) if maker == "cfg3" else workloads.cfg5(0.1875, nshots=9)
     wav = w.wavelet()
 
     def mk():
