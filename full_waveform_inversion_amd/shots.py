@@ -128,15 +128,25 @@ class HostExchange:
 class EnginePool:
     """Several engines (contexts + streams) on ONE GPU working through a rank's shots concurrently.
 
-    A 2-D shot is latency-bound and cannot fill an MI355X (1024^2: 7 us/step alone, 3.5 us/step/shot
-    with four in flight); independent shots overlap when each has its own context and is driven
-    by its own host thread (ctypes releases the GIL during the C-ABI calls).  3-D shots are
-    bandwidth-bound: use a pool of one.  Engines after the first only add into the first one's
-    gradient accumulator, which also owns the RCCL communicator.
+    A 2-D shot is latency-bound and cannot fill an MI355X; independent shots overlap when each has its own
+    context and is driven by its own host thread (ctypes releases the GIL during the C-ABI calls).  Measured
+    on configs[2] (32 shots of 1024^2 x 2000 steps, forward + adjoint + imaging): 0.44 s one after the other,
+    0.35 s with two contexts, 0.35 - 0.38 s with three to six, 1.06 s with eight -- more streams than the
+    runtime has hardware queues for serialise and pay for it; hence ``MAX_USEFUL``.  3-D shots are
+    bandwidth-bound: use a pool of one.  Engines after the first only add into the first one's gradient
+    accumulator, which also owns the RCCL communicator.
     """
 
+    MAX_USEFUL = 6
+
     def __init__(self, make_engine, size):
-        self.engines = [make_engine() for _ in range(max(1, int(size)))]
+        size = max(1, int(size))
+        if size > self.MAX_USEFUL:
+            import warnings
+            warnings.warn("EnginePool of %d contexts on one GPU: beyond %d the streams share hardware queues and the "
+                          "shots slow down (configs[2]: 0.35 s with 2 - 6 contexts, 1.06 s with 8)"
+                          % (size, self.MAX_USEFUL), RuntimeWarning, stacklevel=2)
+        self.engines = [make_engine() for _ in range(size)]
 
     @property
     def primary(self):
