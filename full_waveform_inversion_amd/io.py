@@ -101,32 +101,77 @@ def load_input_data(datadir, real_data_fnames, green_func_fnames, manual_indices
     return real, green
 
 
+def load_input_data_multiple_media(datadir, real_data_fnames, green_func_fnames, green_func_fnames_split_index,
+                                   manual_indices_time_shift=(), cut_phase_start_vals=(), cut_phase_length=0,
+                                   set_pre_time_shift_values_to_zero_switch=True):
+    """The reference's two-media trace loader (:116-165): ``green_func_fnames`` holds the files of medium 1 followed,
+    from ``green_func_fnames_split_index`` on, by the files of medium 2 for the same traces.
+
+    Returns ``real_data_array (k, t)`` and ``green_func_array (k, n, t, 2)`` (last axis = medium); time shift and phase
+    cut as in :func:`load_input_data`, applied to both media alike.
+    """
+    split = int(green_func_fnames_split_index)
+    media = (list(green_func_fnames[:split]), list(green_func_fnames[split:]))
+    if len(media[0]) != len(media[1]):
+        raise ValueError("Green's-function file list does not split into two media of equal length at index %d "
+                         "(%d / %d files)" % (split, len(media[0]), len(media[1])))  # (:123-125 print + exit)
+    real = np.stack([np.loadtxt(os.path.join(datadir, f), dtype=float) for f in real_data_fnames])
+    ntr = len(real_data_fnames)  # the reference loads one Green's-function file per DATA trace (:138)
+    green = np.stack([np.stack([np.transpose(np.loadtxt(os.path.join(datadir, media[m][i]), dtype=float))
+                                for i in range(ntr)]) for m in (0, 1)], axis=3)
+    if len(media[0]) > ntr:  # further files are allocated but never read (:134): zeros
+        green = np.concatenate((green, np.zeros((len(media[0]) - ntr,) + green.shape[1:])), axis=0)
+    if len(manual_indices_time_shift) > 0:
+        rolled = np.zeros_like(green)
+        for i, shift in enumerate(manual_indices_time_shift):
+            rolled[i] = np.roll(green[i], shift, axis=1)
+            if set_pre_time_shift_values_to_zero_switch:
+                rolled[i, :, 0:shift, :] = 0.0
+        green = rolled
+    if len(cut_phase_start_vals) > 0:
+        n = int(cut_phase_length)
+        cut_r = np.zeros((real.shape[0], n))
+        cut_g = np.zeros((green.shape[0], green.shape[1], n, 2))
+        for i in range(ntr):
+            s0 = int(cut_phase_start_vals[i])
+            cut_r[i] = real[i, s0:s0 + n]
+            cut_g[i] = green[i, :, s0:s0 + n, :]
+        real, green = cut_r, cut_g
+    return real, green
+
+
 def get_overall_real_and_green_func_data(datadir, real_data_fnames, MT_green_func_fnames,
                                          single_force_green_func_fnames, inversion_type,
                                          manual_indices_time_shift_MT=(), manual_indices_time_shift_SF=(),
                                          cut_phase_start_vals=(), cut_phase_length=0,
-                                         set_pre_time_shift_values_to_zero_switch=True):
+                                         set_pre_time_shift_values_to_zero_switch=True,
+                                         invert_for_ratio_of_multiple_media_greens_func_switch=False,
+                                         green_func_fnames_split_index=0):
     """Data and Green's functions for an inversion type (:168-197): moment-tensor files for the
     6-component types, single-force files for ``single_force``, both side by side (9 components)
     for the combined types; moment-tensor Green's functions are scaled by 1e3 (units relative to
-    the single-force ones) and everything by 1e7 (SI), as the reference does.  The reference's
-    two-media variant is not provided (it is unreachable from its shipped driver, SURVEY A-8/A-9).
+    the single-force ones) and everything by 1e7 (SI), as the reference does.  With
+    ``invert_for_ratio_of_multiple_media_greens_func_switch`` the file lists hold two media
+    (:func:`load_input_data_multiple_media`) and the Green's functions come back ``(k, n, t, 2)``.
     """
     kw = dict(cut_phase_start_vals=cut_phase_start_vals, cut_phase_length=cut_phase_length,
               set_pre_time_shift_values_to_zero_switch=set_pre_time_shift_values_to_zero_switch)
+    if invert_for_ratio_of_multiple_media_greens_func_switch:
+        def load(datadir, real_fnames, green_fnames, shift, **kw2):
+            return load_input_data_multiple_media(datadir, real_fnames, green_fnames, green_func_fnames_split_index,
+                                                  shift, **kw2)
+    else:
+        load = load_input_data
     if inversion_type in ("full_mt", "DC", "DC_crack_couple"):
-        real, green = load_input_data(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT,
-                                      **kw)
+        real, green = load(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT, **kw)
         green = green * (10 ** 3)
     elif inversion_type == "single_force":
-        real, green = load_input_data(datadir, real_data_fnames, single_force_green_func_fnames,
-                                      manual_indices_time_shift_SF, **kw)
+        real, green = load(datadir, real_data_fnames, single_force_green_func_fnames, manual_indices_time_shift_SF,
+                           **kw)
     elif inversion_type in ("DC_single_force_couple", "DC_single_force_no_coupling",
                             "single_force_crack_no_coupling"):
-        real, mt = load_input_data(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT,
-                                   **kw)
-        real, sf = load_input_data(datadir, real_data_fnames, single_force_green_func_fnames,
-                                   manual_indices_time_shift_SF, **kw)
+        real, mt = load(datadir, real_data_fnames, MT_green_func_fnames, manual_indices_time_shift_MT, **kw)
+        real, sf = load(datadir, real_data_fnames, single_force_green_func_fnames, manual_indices_time_shift_SF, **kw)
         green = np.hstack((mt * (10 ** 3), sf))
     else:
         raise ValueError("unknown inversion_type %r" % (inversion_type,))

@@ -321,12 +321,84 @@ def perform_inversion(real_data_array, green_func_array):
     return np.linalg.lstsq(A, D, rcond=-1)[0]             # rcond=-1: the legacy default the reference ran with
 
 
-def get_synth_forward_model_most_likely_result(MTs, MTp, green_func_array, inversion_type, device=0):
-    """Synthetic of the highest-posterior sample (:974-1020, single-medium branches): the coupled
-    types carry the amplitude fraction as an extra last row, which is not a source component."""
+def get_synth_forward_model_most_likely_result(MTs, MTp, green_func_array, inversion_type, device=0,
+                                               invert_for_ratio_of_multiple_media_greens_func_switch=False,
+                                               green_func_phase_labels=(), num_phase_types_for_media_ratios=0):
+    """Synthetic of the highest-posterior sample (:974-1020): the coupled types carry the amplitude
+    fraction as an extra row, which is not a source component.  Two media (``green_func_array (k, n, t, 2)``): the
+    sample's last row(s) are the fraction(s) of medium 2 -- one, or one per phase type (P, S, surface), every trace
+    mixing its two Green's functions with the fraction of its label -- and the synthetic is formed on that mixture."""
+    MTs = np.asarray(MTs)
     best = int(np.where(MTp == np.max(MTp))[0][0])
-    rows = slice(None, -1) if inversion_type in samplers.COUPLED_TYPES else slice(None)
-    return forward_model(green_func_array, np.asarray(MTs)[rows, best], device)
+    coupled = inversion_type in samplers.COUPLED_TYPES
+    if not invert_for_ratio_of_multiple_media_greens_func_switch:
+        rows = slice(None, -1) if coupled else slice(None)
+        return forward_model(green_func_array, MTs[rows, best], device)
+    G2 = _f64(green_func_array)
+    if num_phase_types_for_media_ratios > 0:
+        frac = dict(zip(PHASE_CLASSES, MTs[-3:, best]))
+        G = np.zeros(G2.shape[:3])
+        for j, lab in enumerate(green_func_phase_labels):  # (traces beyond the labels stay zero, as in :989-992)
+            G[j] = (1.0 - frac[lab]) * G2[j, :, :, 0] + frac[lab] * G2[j, :, :, 1]
+        nextra = 4 if coupled else 3
+    else:
+        f = MTs[-1, best]
+        G = (1.0 - f) * G2[..., 0] + f * G2[..., 1]
+        nextra = 2 if coupled else 1
+    return forward_model(G, MTs[:-nextra, best], device)
+
+
+def run_multi_medium_inversion(datadir, outdir, real_data_fnames, MT_green_func_fnames,
+                               single_force_green_func_fnames, data_labels, inversion_type,
+                               perform_normallised_waveform_inversion, compare_all_waveforms_simultaneously,
+                               num_samples, comparison_metric, manual_indices_time_shift_MT=(),
+                               manual_indices_time_shift_SF=(), uid="event", stations=(), cut_phase_start_vals=(),
+                               cut_phase_length=0, set_pre_time_shift_values_to_zero_switch=True,
+                               only_save_non_zero_solns_switch=False, return_absolute_similarity_values_switch=False,
+                               green_func_fnames_split_index=0, green_func_phase_labels=(), seed=0, device=0,
+                               reference_stream=False):
+    """The reference's two-media driver (:1037-1158): load both media's Green's functions, least-squares estimate on
+    their 50 / 50 mixture (saved under ``<outdir>/least_squares_result``), Monte Carlo inversion for the source AND the
+    fraction(s) of medium 2 on the GPU, result and best-fit waveforms pickled in the reference's layout.
+
+    As written the reference cannot get past its least-squares block: it forms that block's "most likely" synthetic on
+    the 4-D two-media array (:1084-1086), which ``forward_model`` cannot take, and its shipped ``__main__`` never
+    passes the switch on.  Here that synthetic is formed on the same 50 / 50 mixture the
+    estimate was made on; everything else follows the listed lines.  ``uid`` / ``stations`` replace the NonLinLoc file.
+    Returns ``(MTs, MTp, MTp_absolute)`` with the fraction rows appended to ``MTs`` (:855-864).
+    """
+    from . import io
+    real, G2 = io.get_overall_real_and_green_func_data(
+        datadir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, inversion_type,
+        manual_indices_time_shift_MT, manual_indices_time_shift_SF, cut_phase_start_vals, cut_phase_length,
+        set_pre_time_shift_values_to_zero_switch, invert_for_ratio_of_multiple_media_greens_func_switch=True,
+        green_func_fnames_split_index=green_func_fnames_split_index)
+    labels = list(green_func_phase_labels)
+    if labels and len(labels) != G2.shape[0]:
+        raise ValueError("green_func_phase_labels must hold one label per trace (%d traces, %d labels)"
+                         % (G2.shape[0], len(labels)))  # (:1044-1047 print + exit)
+    nphase = sum(1 for c in PHASE_CLASSES if labels.count(c) > 0)  # (:1050-1056)
+    G_lsq = 0.5 * G2[..., 0] + 0.5 * G2[..., 1]  # frac_medium_2 = 0.5 (:1059-1060)
+    M = perform_inversion(real, G_lsq)
+    M_amplitude = float(np.sum(M ** 2) ** 0.5)
+    lsq_sim = compare_synth_to_real_waveforms(real, G_lsq, M, comparison_metric, perform_normallised_waveform_inversion,
+                                              compare_all_waveforms_simultaneously, device)
+    lsq_dir = os.path.join(outdir, "least_squares_result")
+    io.save_to_MTFIT_style_file(M, np.array([lsq_sim]), uid, inversion_type, lsq_dir, stations)
+    io.save_specific_waveforms_to_file(real, forward_model(G_lsq, M, device), data_labels, uid, inversion_type, lsq_dir)
+    MTs, MTp, MTp_absolute = perform_monte_carlo_sampled_waveform_inversion_multiple_media(
+        real, G2, num_samples, M_amplitude, inversion_type, comparison_metric, perform_normallised_waveform_inversion,
+        compare_all_waveforms_simultaneously, labels, nphase, seed=seed, device=device,
+        reference_stream=reference_stream,
+        return_absolute_similarity_values_switch=return_absolute_similarity_values_switch)
+    if np.isnan(MTp[0]):
+        raise FloatingPointError("sum of probabilities is zero: no adequate solution found (:1094-1096)")
+    if only_save_non_zero_solns_switch:
+        MTp, MTs = io.remove_zero_prob_results(MTp, MTs)
+    io.save_to_MTFIT_style_file(MTs, MTp, uid, inversion_type, outdir, stations, MTp_absolute)
+    best = get_synth_forward_model_most_likely_result(MTs, MTp, G2, inversion_type, device, True, labels, nphase)
+    io.save_specific_waveforms_to_file(real, best, data_labels, uid, inversion_type, outdir)
+    return MTs, MTp, MTp_absolute
 
 
 def run(datadir, outdir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, data_labels,

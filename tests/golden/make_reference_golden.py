@@ -23,6 +23,10 @@ get_overall_real_and_green_func_data (:168-197), perform_inversion (:242-251) an
 get_synth_forward_model_most_likely_result (:974-1020), run on text trace files written to a
 temporary directory from the seeded arrays stored alongside the outputs.
 
+ref_multimedia_pipeline.npz pins the two-media host functions: load_input_data_multiple_media (:116-165), the
+two-media switch of get_overall_real_and_green_func_data and the two-media branches of
+get_synth_forward_model_most_likely_result.
+
 Run from the repo root (only where /root/reference exists):
     python tests/golden/make_reference_golden.py
 """
@@ -263,9 +267,76 @@ def pipeline_case(ref, name):
     print(name, "written:", len(out), "arrays")
 
 
+def multimedia_pipeline_case(ref, name):
+    """The two-media host functions: load_input_data_multiple_media (:116-165), the switch of
+    get_overall_real_and_green_func_data (:168-197) and the two-media branches of
+    get_synth_forward_model_most_likely_result (:974-1020; one fraction, and one per phase type, for a coupled and a
+    plain inversion type).  File lists hold medium 1's files followed by medium 2's."""
+    import tempfile
+    rng = np.random.default_rng(78)
+    k, t = 5, 64
+    real = rng.standard_normal((k, t))
+    mt = rng.standard_normal((2, k, 6, t)) * 1e-10   # [medium]
+    sf = rng.standard_normal((2, k, 3, t)) * 1e-7
+    shift_mt, shift_sf = [3, 0, 7, 1, 12], [2, 5, 0, 9, 4]
+    cut_start, cut_len = [10, 0, 23, 20, 28], 36
+    labels = ["P", "S", "surface", "S", "P"]
+    out = {"real": real, "mt": mt, "sf": sf, "shift_mt": shift_mt, "shift_sf": shift_sf, "cut_start": cut_start,
+           "cut_len": cut_len, "labels": np.array(labels)}
+    with tempfile.TemporaryDirectory() as tmp:
+        rn, mn, sn = [], [], []
+        for m in (0, 1):
+            r_, m_, s_ = write_trace_files(tmp, real, mt[m], sf[m])
+            # (write_trace_files names by trace only: give each medium its own names)
+            for lst, src in ((mn, m_), (sn, s_)):
+                for f in src:
+                    g = "m%d_%s" % (m + 1, f)
+                    os.replace(os.path.join(tmp, f), os.path.join(tmp, g))
+                    lst.append(g)
+            rn = r_
+        out["plain_real"], out["plain_green"] = ref.load_input_data_multiple_media(tmp, rn, mn, k)
+        out["shift_real"], out["shift_green"] = ref.load_input_data_multiple_media(tmp, rn, mn, k, shift_mt)
+        out["shiftkeep_real"], out["shiftkeep_green"] = ref.load_input_data_multiple_media(
+            tmp, rn, mn, k, shift_mt, set_pre_time_shift_values_to_zero_switch=False)
+        out["cut_real"], out["cut_green"] = ref.load_input_data_multiple_media(tmp, rn, sn, k, shift_sf, cut_start,
+                                                                               cut_len)
+        for typ in SAMPLERS:
+            r, g = ref.get_overall_real_and_green_func_data(
+                tmp, rn, mn, sn, typ, manual_indices_time_shift_MT=shift_mt, manual_indices_time_shift_SF=shift_sf,
+                cut_phase_start_vals=cut_start, cut_phase_length=cut_len,
+                invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_fnames_split_index=k)
+            out["overall_real_" + typ], out["overall_green_" + typ] = r, g
+            # most likely synthetic: samples with fraction rows appended the way the driver does (:855-864)
+            np.random.seed(6)
+            random.seed(6)
+            cols, fr = [], []
+            for _ in range(6):
+                smp = getattr(ref, SAMPLERS[typ])()
+                cols.append(smp[0] if isinstance(smp, tuple) else smp)
+                fr.append(smp[1] if isinstance(smp, tuple) else 0.0)
+            base = np.hstack(cols)
+            if isinstance(smp, tuple):
+                base = np.vstack((base, np.array(fr)))
+            MTp = np.array([0.1, 0.05, 0.15, 0.2, 0.4, 0.1])
+            for nphase, nfr in ((0, 1), (3, 3)):
+                MTs = np.vstack((base, np.random.uniform(0.0, 1.0, (nfr, 6))))
+                out["ml_MTs_%d_%s" % (nphase, typ)] = MTs
+                out["ml_synth_%d_%s" % (nphase, typ)] = ref.get_synth_forward_model_most_likely_result(
+                    MTs, MTp, g, typ, invert_for_ratio_of_multiple_media_greens_func_switch=True,
+                    green_func_phase_labels=labels, num_phase_types_for_media_ratios=nphase)
+            out["ml_MTp"] = MTp
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "written:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ref = load_reference()
+    if len(sys.argv) > 1:  # only the named cases, e.g. `... make_reference_golden.py multimedia_pipeline`
+        for nm in sys.argv[1:]:
+            globals()[nm + "_case"](ref, "ref_" + nm)
+        sys.exit(0)
     pipeline_case(ref, "ref_pipeline")
+    multimedia_pipeline_case(ref, "ref_multimedia_pipeline")
     samplers_case(ref, "ref_samplers")
     multimedia_case(ref, "ref_multimedia")
     case(ref, "ref_mc_fullmt", 0, 5, 6, 160, 24, "full_mt")

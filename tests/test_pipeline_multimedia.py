@@ -1,0 +1,116 @@
+"""The TWO-MEDIA host functions either side of the Monte Carlo loop against the REFERENCE's outputs
+(tests/golden/ref_multimedia_pipeline.npz, made by tests/golden/make_reference_golden.py): the two-media trace loader
+(full_waveform_inversion.py:116-165), the two-media switch of get_overall_real_and_green_func_data (:168-197) and -- on
+the GPU -- the two-media branches of get_synth_forward_model_most_likely_result (:974-1020) and the whole
+run_multi_medium_inversion (:1037-1158; the reference's own cannot run, see its docstring here)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import io, samplers, source_inversion as si
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_multimedia_pipeline.npz"))
+K = Z["real"].shape[0]
+
+
+def write_two_media_files(datadir, real, mt, sf):
+    """Data files, then per Green's-function kind the list [medium 1's files..., medium 2's files...]."""
+    rn, mn, sn = [], [], []
+    for i in range(real.shape[0]):
+        rn.append("real_%02d.txt" % i)
+        np.savetxt(os.path.join(datadir, rn[-1]), real[i], fmt="%.18e")
+    for m in (0, 1):
+        for lst, stem, arr in ((mn, "m%d_gf_mt_%02d.txt", mt[m]), (sn, "m%d_gf_sf_%02d.txt", sf[m])):
+            for i in range(real.shape[0]):
+                lst.append(stem % (m + 1, i))
+                np.savetxt(os.path.join(datadir, lst[-1]), arr[i].T, fmt="%.18e")
+    return rn, mn, sn
+
+
+@pytest.fixture(scope="module")
+def traces(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("traces2"))
+    return (d,) + write_two_media_files(d, Z["real"], Z["mt"], Z["sf"])
+
+
+def test_two_media_loader_vs_reference(traces):
+    d, rn, mn, sn = traces
+    shift_mt, shift_sf = list(Z["shift_mt"]), list(Z["shift_sf"])
+    for key, got in (("plain", io.load_input_data_multiple_media(d, rn, mn, K)),
+                     ("shift", io.load_input_data_multiple_media(d, rn, mn, K, shift_mt)),
+                     ("shiftkeep", io.load_input_data_multiple_media(d, rn, mn, K, shift_mt,
+                                                                     set_pre_time_shift_values_to_zero_switch=False)),
+                     ("cut", io.load_input_data_multiple_media(d, rn, sn, K, shift_sf, list(Z["cut_start"]),
+                                                               int(Z["cut_len"])))):
+        assert np.array_equal(got[0], Z[key + "_real"]) and np.array_equal(got[1], Z[key + "_green"]), key
+    assert Z["plain_green"].shape == (K, 6, Z["real"].shape[1], 2) and Z["cut_green"].shape == (K, 3, int(Z["cut_len"]), 2)
+    with pytest.raises(ValueError):
+        io.load_input_data_multiple_media(d, rn, mn, K + 1)  # the list does not split into two equal halves
+
+
+@pytest.mark.parametrize("typ", samplers.INVERSION_TYPES)
+def test_two_media_overall_data_vs_reference(traces, typ):
+    d, rn, mn, sn = traces
+    real, green = io.get_overall_real_and_green_func_data(
+        d, rn, mn, sn, typ, list(Z["shift_mt"]), list(Z["shift_sf"]), list(Z["cut_start"]), int(Z["cut_len"]),
+        invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_fnames_split_index=K)
+    assert np.array_equal(real, Z["overall_real_" + typ])
+    assert green.shape == (K, samplers.NUM_COMPONENTS[typ], int(Z["cut_len"]), 2)
+    assert np.allclose(green, Z["overall_green_" + typ], rtol=1e-15, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nphase", [0, 3])
+@pytest.mark.parametrize("typ", samplers.INVERSION_TYPES)
+def test_two_media_most_likely_synthetic_vs_reference(gpu, typ, nphase):
+    synth = si.get_synth_forward_model_most_likely_result(
+        Z["ml_MTs_%d_%s" % (nphase, typ)], Z["ml_MTp"], Z["overall_green_" + typ], typ,
+        invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_phase_labels=list(Z["labels"]),
+        num_phase_types_for_media_ratios=nphase)
+    ref = Z["ml_synth_%d_%s" % (nphase, typ)]
+    assert synth.shape == ref.shape and np.allclose(synth, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ,labels", [("full_mt", ["P", "S", "surface", "S", "P"]), ("DC_single_force_no_coupling", [])])
+def test_run_multi_medium_inversion_writes_the_reference_layout(gpu, traces, tmp_path, typ, labels):
+    """Data synthesised from a known source in a known mixture of the two media: the least-squares estimate on the
+    50 / 50 mixture and the Monte Carlo run produce files in the reference's layout, the fraction rows are appended to
+    the samples, and the best sample fits better than the median one."""
+    d, rn, mn, sn = traces
+    real, G2 = io.get_overall_real_and_green_func_data(
+        d, rn, mn, sn, typ, invert_for_ratio_of_multiple_media_greens_func_switch=True, green_func_fnames_split_index=K)
+    n = samplers.NUM_COMPONENTS[typ]
+    M_true = np.random.default_rng(4).standard_normal(n)
+    G_mix = 0.5 * G2[..., 0] + 0.5 * G2[..., 1]
+    synth = np.einsum("kjt,j->kt", G_mix, M_true)
+    dd = str(tmp_path / "data")
+    os.makedirs(dd)
+    rn2, mn2, sn2 = write_two_media_files(dd, synth, Z["mt"], Z["sf"])
+    out = str(tmp_path / "out")
+    names = ["ST%02d, Z" % i for i in range(K)]
+    N = 20000
+    MTs, MTp, MTp_abs = si.run_multi_medium_inversion(
+        dd, out, rn2, mn2, sn2, names, typ, False, False, N, "VR", uid="ev2", stations=["ST00"],
+        return_absolute_similarity_values_switch=True, green_func_fnames_split_index=K,
+        green_func_phase_labels=labels, seed=5)
+    coupled = typ in samplers.COUPLED_TYPES
+    nfrac = 3 if labels else 1
+    assert MTs.shape == (n + coupled + nfrac, N) and abs(MTp.sum() - 1) < 1e-9 and MTp_abs.shape == (N,)
+    assert np.all((MTs[-nfrac:] >= 0.0) & (MTs[-nfrac:] <= 1.0))
+    with open(os.path.join(out, "least_squares_result", "ev2_FW_%s.pkl" % typ), "rb") as f:
+        lsq = pickle.load(f)
+    assert np.allclose(lsq["MTs"][:, 0], M_true, rtol=1e-6) and lsq["MTp"][0] > 0.999999
+    with open(os.path.join(out, "ev2_FW_%s.pkl" % typ), "rb") as f:
+        res = pickle.load(f)
+    assert sorted(res) == ["MTp", "MTp_absolute", "MTs", "stations", "uid"] and np.array_equal(res["MTs"], MTs)
+    with open(os.path.join(out, "ev2_FW_%s.wfs" % typ), "rb") as f:
+        wfs = pickle.load(f)
+    assert sorted(wfs) == sorted(names) and np.array_equal(wfs[names[1]]["real_wf"], synth[1])
+    best = int(np.argmax(MTp))
+    assert MTp_abs[best] > np.median(MTp_abs)
+    # the saved best-fit synthetic is the best sample's source on ITS mixture of the media
+    again = si.get_synth_forward_model_most_likely_result(MTs, MTp, G2, typ, 0, True, labels, len(set(labels)))
+    assert np.allclose(wfs[names[3]]["synth_wf"], again[3], rtol=1e-12, atol=0)
