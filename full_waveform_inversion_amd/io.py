@@ -44,6 +44,45 @@ def load_shots(path):
     return shots, float(z["dt"])
 
 
+def get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file(nlloc_hyp_filename):
+    """Event uid and station list from a NonLinLoc ``.hyp`` file (:872-946), without obspy or shell tools.
+
+    The reference greps the ``GEOGRAPHIC`` line (origin time = its fields 2-7: year month day hour minute seconds)
+    and the lines between ``PHASE ID`` and ``END_PHASE`` (field 0 station, 4 phase, 22 azimuth, 24 ray take-off
+    angle), and builds ``uid = strftime("%Y%m%d%H%M%S%f")`` and one MTFIT-style entry per station that has a P phase:
+    ``[name (1,), azimuth (1, 1), 180 - take-off (1, 1), polarity 0 (1, 1)]``.  NOT pinned to the reference: its
+    function needs obspy's ``UTCDateTime``, which is absent here (the only unpinned function of the source-inversion
+    side); stations come in order of first appearance (the reference's order is Python 2's dict order).
+    """
+    geo, phases, inside = None, [], False
+    with open(nlloc_hyp_filename) as f:
+        for line in f:
+            if "GEOGRAPHIC" in line and geo is None:
+                geo = line.split()
+            if "END_PHASE" in line:
+                inside = False
+            elif inside and line.strip():
+                phases.append(line.split())
+            elif "PHASE ID" in line:
+                inside = True
+    if geo is None or len(geo) < 8:
+        raise ValueError("%s: no GEOGRAPHIC line with an origin time" % nlloc_hyp_filename)
+    sec = float(geo[7])
+    micro = int(round((sec - int(sec)) * 1e6))
+    carry, micro = divmod(micro, 1000000)
+    import datetime
+    t0 = datetime.datetime(int(geo[2]), int(geo[3]), int(geo[4]), int(geo[5]), int(geo[6]), int(sec)) \
+        + datetime.timedelta(seconds=carry, microseconds=micro)
+    uid = t0.strftime("%Y%m%d%H%M%S%f")
+    angles = {}
+    for p in phases:
+        if len(p) > 24 and p[4] == "P":
+            angles[p[0]] = (float(p[22]), 180.0 - float(p[24]))  # (a later P line of a station overrides, as :927-929)
+    stations = [[np.array([name], dtype=str), np.array([[azi]], dtype=float), np.array([[toa]], dtype=float),
+                 np.array([[0]], dtype=int)] for name, (azi, toa) in angles.items()]
+    return uid, stations
+
+
 def save_to_MTFIT_style_file(MTs, MTp, uid, inversion_type, outdir, stations=(), MTp_absolute=()):
     """``<outdir>/<uid>_FW_<inversion_type>.pkl`` with keys MTs, MTp, uid, stations[, MTp_absolute]
     -- the dict of the reference's writer (:955-971)."""

@@ -356,7 +356,7 @@ def run_multi_medium_inversion(datadir, outdir, real_data_fnames, MT_green_func_
                                cut_phase_length=0, set_pre_time_shift_values_to_zero_switch=True,
                                only_save_non_zero_solns_switch=False, return_absolute_similarity_values_switch=False,
                                green_func_fnames_split_index=0, green_func_phase_labels=(), seed=0, device=0,
-                               reference_stream=False):
+                               reference_stream=False, nlloc_hyp_filename=None):
     """The reference's two-media driver (:1037-1158): load both media's Green's functions, least-squares estimate on
     their 50 / 50 mixture (saved under ``<outdir>/least_squares_result``), Monte Carlo inversion for the source AND the
     fraction(s) of medium 2 on the GPU, result and best-fit waveforms pickled in the reference's layout.
@@ -368,6 +368,8 @@ def run_multi_medium_inversion(datadir, outdir, real_data_fnames, MT_green_func_
     Returns ``(MTs, MTp, MTp_absolute)`` with the fraction rows appended to ``MTs`` (:855-864).
     """
     from . import io
+    if nlloc_hyp_filename:
+        uid, stations = io.get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file(nlloc_hyp_filename)
     real, G2 = io.get_overall_real_and_green_func_data(
         datadir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, inversion_type,
         manual_indices_time_shift_MT, manual_indices_time_shift_SF, cut_phase_start_vals, cut_phase_length,
@@ -406,15 +408,19 @@ def run(datadir, outdir, real_data_fnames, MT_green_func_fnames, single_force_gr
         comparison_metric, manual_indices_time_shift_MT=(), manual_indices_time_shift_SF=(), uid="event",
         stations=(), cut_phase_start_vals=(), cut_phase_length=0, set_pre_time_shift_values_to_zero_switch=True,
         only_save_non_zero_solns_switch=False, return_absolute_similarity_values_switch=False, seed=0, device=0,
-        reference_stream=False):
+        reference_stream=False, nlloc_hyp_filename=None):
     """The reference's ``run`` (:1161-1233) for one set of Green's functions: load the traces,
     least-squares estimate (saved under ``<outdir>/least_squares_result``), Monte Carlo inversion
     on the GPU scaled to the least-squares amplitude, result and best-fit waveforms pickled in the
     reference's layout.  ``uid`` / ``stations`` replace the NonLinLoc file the reference reads them
     from (needs obspy); plotting is left to the reference's plotting script, which reads the
-    files written here.  Returns ``(MTs, MTp, MTp_absolute)``.
+    files written here.  ``nlloc_hyp_filename``: take ``uid`` / ``stations`` from that NonLinLoc file
+    instead (``io.get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file``).
+    Returns ``(MTs, MTp, MTp_absolute)``.
     """
     from . import io
+    if nlloc_hyp_filename:
+        uid, stations = io.get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file(nlloc_hyp_filename)
     real, G = io.get_overall_real_and_green_func_data(
         datadir, real_data_fnames, MT_green_func_fnames, single_force_green_func_fnames, inversion_type,
         manual_indices_time_shift_MT, manual_indices_time_shift_SF, cut_phase_start_vals, cut_phase_length,

@@ -104,3 +104,32 @@ def test_run_writes_the_reference_layout(gpu, traces, tmp_path, typ):
         assert np.allclose(np.linalg.norm(MTs, axis=0), amp, rtol=1e-9)
     best = int(np.argmax(MTp))
     assert MTp_abs[best] > np.median(MTp_abs)
+
+
+HYP = """NLLOC "x" "LOCATED" "Location completed."
+GEOGRAPHIC  OT 2014 06 29  18 42   10.123456  Lat -75.1 Long -84.2 Depth 2.0
+PHASE ID Ins Cmp On Pha  FM Date     HrMn   Sec     Err  ErrMag    Coda      Amp       Per  >   TTpred    Res       Weight    StaLoc(X  Y         Z)        SDist    SAzim  RAz  RDip RQual    Tcorr
+ST01   ?    ?    ? P      ? 20140629 1842   10.5000 GAU  2.00e-02 -1.00e+00 -1.00e+00 -1.00e+00 >     0.3770  0.0000    1.0000    1.0000    2.0000    0.0000    0.8000 110.00 110.0  95.0  9     0.0000
+ST01   ?    ?    ? S      ? 20140629 1842   10.9000 GAU  2.00e-02 -1.00e+00 -1.00e+00 -1.00e+00 >     0.7770  0.0000    1.0000    1.0000    2.0000    0.0000    0.8000 110.00 111.0  96.0  9     0.0000
+ST03   ?    ?    ? S      ? 20140629 1842   11.2000 GAU  2.00e-02 -1.00e+00 -1.00e+00 -1.00e+00 >     0.9770  0.0000    1.0000    5.0000    2.0000    0.0000    1.8000  10.00  11.0  70.0  9     0.0000
+ST02   ?    ?    ? P      ? 20140629 1842   10.6000 GAU  2.00e-02 -1.00e+00 -1.00e+00 -1.00e+00 >     0.4770  0.0000    1.0000    3.0000    1.0000    0.0000    0.9000 250.00 250.5 100.0  9     0.0000
+END_PHASE
+END_NLLOC
+"""
+
+
+def test_nonlinloc_hyp_reader(tmp_path):
+    """Event uid and MTFIT-style station entries from a NonLinLoc .hyp file (:872-946, restated without obspy / grep /
+    awk; not pinned: the reference's function needs obspy): origin time -> uid with microseconds, one entry per
+    station with a P phase (azimuth = field 22, take-off = 180 - field 24), polarity 0."""
+    f = tmp_path / "event.hyp"
+    f.write_text(HYP)
+    uid, stations = io.get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file(str(f))
+    assert uid == "20140629184210123456"
+    assert [s[0][0] for s in stations] == ["ST01", "ST02"]          # ST03 has no P phase
+    assert [float(s[1][0, 0]) for s in stations] == [110.0, 250.0]
+    assert [float(s[2][0, 0]) for s in stations] == [85.0, 80.0]
+    assert all(s[1].shape == s[2].shape == s[3].shape == (1, 1) and int(s[3][0, 0]) == 0 for s in stations)
+    (tmp_path / "bad.hyp").write_text("NLLOC\nEND_NLLOC\n")
+    with pytest.raises(ValueError):
+        io.get_event_uid_and_station_data_MTFIT_FORMAT_from_nonlinloc_hyp_file(str(tmp_path / "bad.hyp"))

@@ -92,21 +92,25 @@ def test_run_multi_medium_inversion_writes_the_reference_layout(gpu, traces, tmp
     out = str(tmp_path / "out")
     names = ["ST%02d, Z" % i for i in range(K)]
     N = 20000
+    from test_pipeline import HYP
+    hyp = tmp_path / "ev2.hyp"
+    hyp.write_text(HYP)  # uid / stations from a NonLinLoc file, as the reference takes them
     MTs, MTp, MTp_abs = si.run_multi_medium_inversion(
-        dd, out, rn2, mn2, sn2, names, typ, False, False, N, "VR", uid="ev2", stations=["ST00"],
+        dd, out, rn2, mn2, sn2, names, typ, False, False, N, "VR", nlloc_hyp_filename=str(hyp),
         return_absolute_similarity_values_switch=True, green_func_fnames_split_index=K,
         green_func_phase_labels=labels, seed=5)
     coupled = typ in samplers.COUPLED_TYPES
     nfrac = 3 if labels else 1
     assert MTs.shape == (n + coupled + nfrac, N) and abs(MTp.sum() - 1) < 1e-9 and MTp_abs.shape == (N,)
     assert np.all((MTs[-nfrac:] >= 0.0) & (MTs[-nfrac:] <= 1.0))
-    with open(os.path.join(out, "least_squares_result", "ev2_FW_%s.pkl" % typ), "rb") as f:
+    with open(os.path.join(out, "least_squares_result", "20140629184210123456_FW_%s.pkl" % typ), "rb") as f:
         lsq = pickle.load(f)
     assert np.allclose(lsq["MTs"][:, 0], M_true, rtol=1e-6) and lsq["MTp"][0] > 0.999999
-    with open(os.path.join(out, "ev2_FW_%s.pkl" % typ), "rb") as f:
+    with open(os.path.join(out, "20140629184210123456_FW_%s.pkl" % typ), "rb") as f:
         res = pickle.load(f)
     assert sorted(res) == ["MTp", "MTp_absolute", "MTs", "stations", "uid"] and np.array_equal(res["MTs"], MTs)
-    with open(os.path.join(out, "ev2_FW_%s.wfs" % typ), "rb") as f:
+    assert res["uid"] == "20140629184210123456" and [s[0][0] for s in res["stations"]] == ["ST01", "ST02"]
+    with open(os.path.join(out, "20140629184210123456_FW_%s.wfs" % typ), "rb") as f:
         wfs = pickle.load(f)
     assert sorted(wfs) == sorted(names) and np.array_equal(wfs[names[1]]["real_wf"], synth[1])
     best = int(np.argmax(MTp))
