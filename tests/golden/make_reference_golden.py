@@ -27,6 +27,10 @@ ref_multimedia_pipeline.npz pins the two-media host functions: load_input_data_m
 two-media switch of get_overall_real_and_green_func_data and the two-media branches of
 get_synth_forward_model_most_likely_result.
 
+ref_names.npz pins the small module-level functions `reference_api` re-exposes under the reference's names: the tensor
+helpers (:199-241), the similarity measures on one pair of 1-D arrays (:512-582) and the dispatcher on a precomputed
+synthetic (:584-684).
+
 Run from the repo root (only where /root/reference exists):
     python tests/golden/make_reference_golden.py
 """
@@ -329,6 +333,36 @@ def multimedia_pipeline_case(ref, name):
     print(name, "written:", len(out), "arrays")
 
 
+def names_case(ref, name):
+    """Inputs / outputs of the reference's small module-level functions, for `reference_api` (same names, same positional
+    signatures): the tensor helpers (:199-241), the similarity measures on ONE pair of 1-D arrays (:512-582, incl. the
+    unused variance_reduction_normallised) and the dispatcher on a precomputed synthetic (:584-684)."""
+    rng = np.random.default_rng(91)
+    out = {}
+    mt = rng.standard_normal(6)
+    full = ref.get_full_MT_array(mt)
+    theta, phi = 0.7, -2.1
+    force = rng.standard_normal(3)
+    out.update(mt=mt, full=full, theta=theta, phi=phi, force=force, six_back=ref.get_six_MT_from_full_MT_array(full),
+               eig=np.array(ref.find_eigenvalues_from_sixMT(mt)), rot_mt=ref.rot_mt_by_theta_phi(full, theta, phi),
+               rot_mt_default=ref.rot_mt_by_theta_phi(full), rot_force=ref.rot_single_force_by_theta_phi(force, theta, phi))
+    G, d, M_true = make_inputs(17, 4, 6, 128)
+    synth = ref.forward_model(G, M_true + 0.3 * rng.standard_normal((6, 1)))
+    out.update(d=d, synth=synth)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for fn in ("variance_reduction", "variance_reduction_normallised", "cross_corr_comparison",
+                   "cross_corr_comparison_shift_allowed", "pearson_correlation_comparison", "gaussian_comparison"):
+            out["pair_" + fn] = np.array([getattr(ref, fn)(d[i], synth[i]) for i in range(d.shape[0])])
+        for metric in METRICS:
+            for norm in (False, True):
+                for allat in (False, True):
+                    out["cmp_%s_%d_%d" % (metric, norm, allat)] = ref.compare_synth_to_real_waveforms(
+                        d, synth, metric, norm, allat)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "written:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     ref = load_reference()
     if len(sys.argv) > 1:  # only the named cases, e.g. `... make_reference_golden.py multimedia_pipeline`
@@ -337,6 +371,7 @@ if __name__ == "__main__":
         sys.exit(0)
     pipeline_case(ref, "ref_pipeline")
     multimedia_pipeline_case(ref, "ref_multimedia_pipeline")
+    names_case(ref, "ref_names")
     samplers_case(ref, "ref_samplers")
     multimedia_case(ref, "ref_multimedia")
     case(ref, "ref_mc_fullmt", 0, 5, 6, 160, 24, "full_mt")

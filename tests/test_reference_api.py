@@ -1,0 +1,113 @@
+"""`full_waveform_inversion_amd.reference_api`: the reference's module-level function names and positional signatures.
+Outputs against the REFERENCE's own (tests/golden/ref_names.npz, ref_samplers.npz -- made by running its functions in
+memory, tests/golden/make_reference_golden.py); the measures and the driver run on the GPU."""
+import inspect
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import reference_api as fw
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+Z = np.load(os.path.join(GOLD, "ref_names.npz"))
+REF_SRC = "/root/reference/full_waveform_inversion.py"
+
+
+def test_tensor_helpers_vs_reference():
+    assert np.array_equal(fw.get_full_MT_array(Z["mt"]), Z["full"])
+    assert np.array_equal(fw.get_six_MT_from_full_MT_array(Z["full"]), Z["six_back"])
+    assert np.allclose(fw.find_eigenvalues_from_sixMT(Z["mt"]), Z["eig"], rtol=1e-13, atol=1e-14)
+    th, ph = float(Z["theta"]), float(Z["phi"])
+    assert np.allclose(fw.rot_mt_by_theta_phi(Z["full"], th, ph), Z["rot_mt"], rtol=1e-14, atol=1e-15)
+    assert np.allclose(fw.rot_mt_by_theta_phi(Z["full"]), Z["rot_mt_default"], rtol=1e-14, atol=1e-15)
+    assert np.allclose(fw.rot_single_force_by_theta_phi(Z["force"], th, ph), Z["rot_force"], rtol=1e-14, atol=1e-15)
+    d, s = Z["d"], Z["synth"]
+    got = np.array([fw.variance_reduction_normallised(d[i], s[i]) for i in range(d.shape[0])])
+    assert np.allclose(got, Z["pair_variance_reduction_normallised"], rtol=1e-13)
+
+
+def test_samplers_by_name_draw_the_reference_stream():
+    """One sample per call from the global generators: after the same seeding the reference's first draws come out
+    (ref_samplers.npz holds 48 consecutive draws per sampler)."""
+    S = np.load(os.path.join(GOLD, "ref_samplers.npz"))
+    names = {"full_mt": "generate_random_MT", "DC": "generate_random_DC_MT",
+             "single_force": "generate_random_single_force_vector",
+             "DC_single_force_couple": "generate_random_DC_single_force_coupled_tensor",
+             "DC_single_force_no_coupling": "generate_random_DC_single_force_uncoupled_tensor",
+             "DC_crack_couple": "generate_random_DC_crack_coupled_tensor",
+             "single_force_crack_no_coupling": "generate_random_single_force_crack_uncoupled_tensor"}
+    for typ, fn in names.items():
+        seed = int(S["seed_" + typ])
+        np.random.seed(seed)
+        random.seed(seed)
+        ref = S["M_" + typ]
+        for i in range(4):
+            out = getattr(fw, fn)()
+            M = out[0] if isinstance(out, tuple) else out
+            assert M.shape == (ref.shape[0], 1), (typ, M.shape, ref.shape)
+            assert np.allclose(M[:, 0], ref[:, i], rtol=1e-12, atol=1e-14), (typ, i)
+            assert isinstance(out, tuple) == ("frac_" + typ in S.files)
+            if isinstance(out, tuple):
+                assert abs(out[1] - S["frac_" + typ][i]) < 1e-14
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SRC), reason="the reference's source is not on this box")
+def test_names_and_positional_signatures_match_the_reference_text():
+    """Every module-level function of the reference is here under its name with the same positional parameters
+    (read from the reference's text; nothing of it is imported) -- except plotting and the forked worker."""
+    src = open(REF_SRC).read()
+    absent = {"plot_specific_forward_model_result", "PARALLEL_worker_mc_inv"}
+    for m in re.finditer(r"^def (\w+)\((.*?)\):", src, re.M | re.S):
+        name, params = m.group(1), [p.split("=")[0].strip() for p in m.group(2).split(",") if p.strip()]
+        if name in absent:
+            assert not hasattr(fw, name)
+            continue
+        assert hasattr(fw, name), name
+        mine = list(inspect.signature(getattr(fw, name)).parameters)
+        assert mine[:len(params)] == params, (name, mine, params)
+
+
+@pytest.mark.gpu
+def test_measures_and_dispatcher_vs_reference(gpu):
+    d, s = Z["d"], Z["synth"]
+    for fn, tol in (("variance_reduction", 1e-12), ("cross_corr_comparison", 1e-11), ("pearson_correlation_comparison", 1e-11),
+                    ("cross_corr_comparison_shift_allowed", 1e-10), ("gaussian_comparison", 1e-11)):
+        got = np.array([getattr(fw, fn)(d[i], s[i]) for i in range(d.shape[0])])
+        assert np.allclose(got, Z["pair_" + fn], rtol=tol, atol=tol), fn
+    for metric in ("VR", "CC", "PCC", "CC-shift", "gau"):
+        for norm in (0, 1):
+            for allat in (0, 1):
+                got = fw.compare_synth_to_real_waveforms(d, s, metric, bool(norm), bool(allat))
+                ref = float(Z["cmp_%s_%d_%d" % (metric, norm, allat)])
+                assert abs(got - ref) < 1e-10 * max(1.0, abs(ref)), (metric, norm, allat, got, ref)
+
+
+@pytest.mark.gpu
+def test_run_by_the_reference_signature(gpu, tmp_path):
+    """`run(...)` called positionally the way the reference's __main__ does, uid / stations from a NonLinLoc file;
+    with the two-media switch it hands over to the two-media driver (:1164-1167)."""
+    import pickle
+    from test_pipeline import HYP
+    from test_pipeline_multimedia import K, Z as ZM, write_two_media_files
+    hyp = tmp_path / "ev.hyp"
+    hyp.write_text(HYP)
+    dd = str(tmp_path / "data")
+    os.makedirs(dd)
+    rn, mn, sn = write_two_media_files(dd, ZM["real"], ZM["mt"], ZM["sf"])
+    labels = ["ST%02d, Z" % i for i in range(K)]
+    np.random.seed(3)
+    random.seed(3)
+    out1 = str(tmp_path / "one")
+    MTs, MTp, _ = fw.run(dd, out1, rn, mn[:K], sn[:K], labels, "DC", False, False, 2000, "VR", [], [], str(hyp))
+    assert MTs.shape == (6, 2000) and abs(MTp.sum() - 1.0) < 1e-9
+    res = pickle.load(open(os.path.join(out1, "20140629184210123456_FW_DC.pkl"), "rb"))
+    assert res["uid"] == "20140629184210123456" and len(res["stations"]) == 2
+    out2 = str(tmp_path / "two")
+    MTs2, MTp2, _ = fw.run(dd, out2, rn, mn, sn, labels, "single_force", False, False, 2000, "VR", [], [], str(hyp), [], 0,
+                           False, 1, True, False, False, True, K, ["P", "S", "P", "S", "surface"])
+    assert MTs2.shape == (3 + 3, 2000) and os.path.exists(os.path.join(out2, "20140629184210123456_FW_single_force.wfs"))
+    with pytest.raises(NotImplementedError):
+        fw.run(dd, out1, rn, mn[:K], sn[:K], labels, "DC", False, False, 10, "VR", [], [], str(hyp), [], 0, True)
