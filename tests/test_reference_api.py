@@ -54,6 +54,15 @@ def test_samplers_by_name_draw_the_reference_stream():
                 assert abs(out[1] - S["frac_" + typ][i]) < 1e-14
 
 
+def test_refusals_are_loud():
+    """What the GPU path does not implement is refused, not silently ignored (and needs no GPU to say so)."""
+    with pytest.raises(NotImplementedError):
+        fw.cross_corr_comparison_shift_allowed(np.zeros(8), np.zeros(8), 7)
+    with pytest.raises(NotImplementedError):
+        fw.run("d", "o", [], [], [], [], "DC", False, False, 10, "VR", [], [], "x.hyp", [], 0, True)
+    assert not hasattr(fw, "PARALLEL_worker_mc_inv") and not hasattr(fw, "plot_specific_forward_model_result")
+
+
 @pytest.mark.skipif(not os.path.exists(REF_SRC), reason="the reference's source is not on this box")
 def test_names_and_positional_signatures_match_the_reference_text():
     """Every module-level function of the reference is here under its name with the same positional parameters
