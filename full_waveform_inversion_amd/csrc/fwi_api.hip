@@ -91,6 +91,8 @@ struct fwi_ctx {
     // per-shot point sets (device) and their sizes
     int nt = 0, nsrc = 0, nrec = 0;
     bool have_forward = false, have_q = false;
+    bool have_syn = false;  // ctx->series still holds the last forward's synthetics (an adjoint sweep records its
+                            // source-side series into the same buffer)
     bool have_dev_residual = false;  // ctx->amp holds the residual fwi_misfit_l2 formed on the device
     // A point set on the device: original order (sampling, POINT-kernel injection) and the
     // copy sorted by stream-kernel tile with its CSR offsets (fused injection).
@@ -275,9 +277,14 @@ struct Impl {
         a.q_in2 = nullptr;
         a.q_bf16 = ctx->qbf16 ? 1 : 0;
         a.g = (T *)ctx->g_acc;
+        // Star weights NORMALISED by a_1 (the factor a_1 / h^2 lives in the padded C, see finish_model): in fp32 the
+        // rounded a_k / h^2 are a systematic perturbation of the operator -- a phase error growing with omega T that
+        // was the largest term of the fp32 seismogram error (2-D layered 256^2 x 1000 steps in emulation: 3.4e-6 ->
+        // 1.8e-6 standard form, 2.9e-6 -> 7.7e-7 increment form).  Normalised, a_1 -> 1 and a_2 -> -1/8 (O(8)) or
+        // -1/16 (O(4)) are exact and the inexact a_3, a_4 weigh 0.016 and 0.0011: their rounding no longer matters.
         const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
         for (int k = 0; k < 5; ++k) a.ck[k] = T(0);
-        for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / (ctx->cfg.h * ctx->cfg.h));
+        for (int k = 1; k <= ctx->gd.r; ++k) a.ck[k] = (T)(co[k] / co[1]);
         a.damp = ctx->cfg.npml > 0 && !ctx->cpml;
         a.npml = ctx->cfg.npml;
         a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
@@ -335,10 +342,17 @@ struct Impl {
         }
         const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
         const double *dc = ctx->cfg.order == 2 ? DCOEF2 : ctx->cfg.order == 4 ? DCOEF4 : DCOEF8;
+        // The padded C carries a_1 / h^2 (base_args), so the border term is formed times s = h^2 / a_1: the second
+        // differences take the normalised weights, the first differences that act on the FIELD (inside the psi / pt
+        // recursions) take dk1 = s d_k / h, those that act on a memory variable the plain d_k / h.  The memory
+        // variables are thereby carried times s, which nothing outside these kernels sees.
         const double h = ctx->cfg.h;
-        for (int k = 0; k < 5; ++k) p.ck[k] = p.dk[k] = T(0);
-        for (int k = 0; k <= ctx->gd.r; ++k) p.ck[k] = (T)(co[k] / (h * h));
-        for (int k = 1; k <= ctx->gd.r; ++k) p.dk[k] = (T)(dc[k - 1] / h);
+        for (int k = 0; k < 5; ++k) p.ck[k] = p.dk[k] = p.dk1[k] = T(0);
+        for (int k = 0; k <= ctx->gd.r; ++k) p.ck[k] = (T)(co[k] / co[1]);
+        for (int k = 1; k <= ctx->gd.r; ++k) {
+            p.dk[k] = (T)(dc[k - 1] / h);
+            p.dk1[k] = (T)(dc[k - 1] * h / co[1]);
+        }
         p.npml = ctx->cfg.npml;
         return p;
     }
@@ -417,7 +431,10 @@ struct Impl {
         hipStream_t s = ctx->stream;
         int *bad = (int *)(ctx->red + 4);
         HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), s));
-        HIPCHK(ctx, launch_build_model<T>(g, (const T *)ctx->c_dev, (T *)ctx->C, ctx->cfg.dt * ctx->cfg.dt, bad, s));
+        // padded C = dt^2 c^2 a_1 / h^2: the kernels' star weights are normalised by a_1 (base_args)
+        const double *co = ctx->cfg.order == 2 ? COEF2 : ctx->cfg.order == 4 ? COEF4 : COEF8;
+        HIPCHK(ctx, launch_build_model<T>(g, (const T *)ctx->c_dev, (T *)ctx->C,
+                                          ctx->cfg.dt * ctx->cfg.dt * co[1] / (ctx->cfg.h * ctx->cfg.h), bad, s));
         int nbad = 0;
         HIPCHK(ctx, hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
@@ -442,7 +459,7 @@ struct Impl {
             const int z = t[0], y = (g.ndim == 3) ? t[1] : 0, x = t[g.ndim - 1];
             const double cv = (double)cpt[i];
             const double d = ctx->pz[z] + ((g.ndim == 3) ? ctx->py[y] : 0.0) + ctx->px[x];
-            const double Cv = (double)(T)(dt2 * cv * cv);  // as the kernels see it
+            const double Cv = dt2 * cv * cv;  // dt^2 c^2 itself (the padded C of the kernels carries a_1 / h^2 as well)
             cq[i] = (T)(Cv * scale);
             cu[i] = (T)(Cv * scale / (1.0 + d));
         }
@@ -786,7 +803,24 @@ struct Impl {
                     a.rec_scale = out_scale;
                     a.nrec = out->n;
                 }
-                HIPCHK(ctx, launch_fused2d(g, a, ctx->stream));
+                if (ctx->cpml) {  // the border recursion inside the launch (fwi_fused2d_pml.hip)
+                    const PmlArgs<T> p = pml_args(ctx, sw, nullptr);
+                    a.pml_npml = p.npml;
+                    a.pml_rev = dn < 0;
+                    for (int d = 0; d < 2; ++d) {  // z -> 0, x -> 1
+                        a.pml_psi[d] = (float *)p.psi[d ? 2 : 0];
+                        a.pml_zeta[d] = (float *)p.zeta[d ? 2 : 0];
+                        a.pml_a[d] = (const float *)p.a[d ? 2 : 0];
+                        a.pml_b[d] = (const float *)p.b[d ? 2 : 0];
+                    }
+                    for (int k = 0; k < 5; ++k) {
+                        a.pml_dk[k] = (float)p.dk[k];
+                        a.pml_dk1[k] = (float)p.dk1[k];
+                    }
+                    HIPCHK(ctx, launch_fused2d_cpml(g, a, ctx->stream));
+                } else {
+                    HIPCHK(ctx, launch_fused2d(g, a, ctx->stream));
+                }
                 if (ctx->inc) {
                     // (u, v) written into the spare pair; the old u and v buffers become the next launch's output.
                     // The second u buffer of the sweep (the single-step kernels' output) is not involved.
@@ -966,6 +1000,7 @@ struct Impl {
         ctx->nrec = nrec;
         ctx->have_forward = false;
         ctx->have_q = false;
+        ctx->have_syn = false;
         ctx->have_dev_residual = false;
         hipStream_t s = ctx->stream;
         if (nsrc && (rc = upload_amplitudes(ctx, ctx->wav, wavelet, nt, nsrc, ctx->src_sp))) return rc;
@@ -1041,6 +1076,7 @@ struct Impl {
                                    &ctx->pts_d, &ctx->cap_pts_d)))
             return rc;
         ctx->have_forward = true;
+        ctx->have_syn = true;
         ctx->have_q = save != 0;
         return FWI_OK;
     }
@@ -1053,6 +1089,7 @@ struct Impl {
         if (ctx->nrec && residual && (rc = upload_amplitudes(ctx, ctx->amp, residual, nt, ctx->nrec, ctx->rec_sp)))
             return rc;  // (residual == nullptr: the one fwi_misfit_l2 left in ctx->amp)
         ctx->have_dev_residual = false;  // consumed: ctx->series is about to be overwritten
+        ctx->have_syn = false;           // ... by this sweep's source-side series (fwi_misfit_l2 must not read them)
         const T rs = (T)(1.0 / std::pow(ctx->cfg.h, g.ndim));
         if ((rc = zero_fields(ctx, ctx->u[0], ctx->u[1]))) return rc;
         Sweep sw;
@@ -1104,6 +1141,7 @@ struct Impl {
             fw.f[0] = ctx->fwd[0];
             fw.f[1] = ctx->fwd[1];
             fw.v = ctx->fwv;
+            fw.pml_fw = true;
             void *fspare[2] = {ctx->fwx[0], ctx->fwx[1]};
             const int nseg = (nt + K - 1) / K;
             for (int seg = nseg - 1; seg >= 0; --seg) {
@@ -1113,6 +1151,7 @@ struct Impl {
                 HIPCHK(ctx, hipMemcpyAsync(fw.f[0], sn, (size_t)g.ptot * sizeof(T), hipMemcpyDeviceToDevice, s));
                 HIPCHK(ctx, hipMemcpyAsync(ctx->inc ? fw.v : fw.f[1], sn + g.ptot, (size_t)g.ptot * sizeof(T),
                                            hipMemcpyDeviceToDevice, s));
+                if (ctx->cpml && (rc = pml_snapshot(ctx, seg, true, true))) return rc;
                 T *qb = q_store - (size_t)n0 * g.npts;  // slot (n - n0) == qb + n * npts
                 if ((rc = run_fused(ctx, fw, fspare, n0, 1, cnt, ctx->src, (const T *)ctx->wav, nullptr, nullptr,
                                     T(0), 1, qb)))
@@ -1489,11 +1528,15 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     }
     // 2-D fp32 grids: advance FUSED2D_STEPS time steps per launch (fwi_fused2d.hip) whenever the step
     // count allows it (FWI_NO_FUSED2D is the tuning / comparison hook)
-    // (the CPML's slab kernels run between time steps: one step per launch, the tile kernel)
+    // (CPML: the fused kernel carries the border recursion itself where the tiling admits it, fused2d_cpml_supported;
+    // otherwise the slab kernels run between time steps: one step per launch, the tile kernel.  FWI_NO_FUSED2D_CPML is
+    // the comparison hook)
     // Increment form in 2-D: the fused kernel carries it (same traffic as the standard form); the steps it cannot take
     // (step counts off the multiple of 4) go through the point kernel, which ctx->kernel names in that case.
     if (const char *sk = getenv("FWI_FUSED2D_SKIPD")) ctx->fused_skipd = atoi(sk) != 0;  // tuning / test hook
-    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && !ctx->cpml && !getenv("FWI_NO_FUSED2D") &&
+    const bool cpml_in_launch = ctx->cpml && !ctx->inc && ctx->kernel == K_STREAM &&
+                                fused2d_cpml_supported(ctx->gd, cfg->npml) && !getenv("FWI_NO_FUSED2D_CPML");
+    ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && (!ctx->cpml || cpml_in_launch) && !getenv("FWI_NO_FUSED2D") &&
                    (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
     // =1 is the tuning / comparison hook)
@@ -1669,6 +1712,9 @@ int fwi_misfit_l2(fwi_ctx *ctx, const void *d_obs, double *J_out) {
     if (!ctx) return FWI_EINVAL;
     if (!ctx->have_forward) return ctx->fail(FWI_ESTATE, "fwi_misfit_l2: no forward run whose data to compare");
     if (!J_out || (ctx->nrec && !d_obs)) return ctx->fail(FWI_EINVAL, "fwi_misfit_l2: null argument");
+    if (!ctx->have_syn)
+        return ctx->fail(FWI_ESTATE, "fwi_misfit_l2: the synthetics of the last forward are gone (an fwi_adjoint has "
+                                     "run since): call it between fwi_forward and fwi_adjoint");
     (void)hipSetDevice(ctx->cfg.device);
     return DISPATCH(ctx, Impl<float>::misfit_l2(ctx, (const float *)d_obs, J_out),
                     Impl<double>::misfit_l2(ctx, (const double *)d_obs, J_out));

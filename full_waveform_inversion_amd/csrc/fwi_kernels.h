@@ -40,7 +40,7 @@ struct StepArgs {
                      // step is v' = A (B v + q), u' = u + v' -- algebraically the same recursion, but the rounding
                      // of u' is relative to u instead of to the cancelling 2u - u_prev (fp32: ~4x smaller error
                      // growth, at 20 instead of 16 B/update: v is read and written, u' written).  nullptr = standard
-    const T *C;      // dt^2 c^2, padded
+    const T *C;      // dt^2 c^2 a_1 / h^2, padded
     const T *dz, *dy, *dx;  // per-axis damping d = sigma dt / 2 (lengths nz, ny, nx)
     T *q_out;        // compact (npts) forward term of this step, or nullptr
     const T *q_in;   // compact forward term to correlate u_cur with, or nullptr
@@ -48,7 +48,7 @@ struct StepArgs {
                      // this term, so the gradient accumulator is read-modified-written every other step
     int q_bf16;      // q_out / q_in / q_in2 point at bf16 arrays (fp32 stream kernel only; fwi_config.store_dtype)
     T *g;            // compact gradient accumulator (used with q_in)
-    T ck[5];         // ck[k] = a_k / h^2, k = 1..r (ck[0] unused)
+    T ck[5];         // ck[k] = a_k / a_1, k = 1..r (ck[0] unused): the factor a_1 / h^2 is folded into C
     int damp;        // npml > 0
     int npml;        // border width; with dz_scale lets the stream kernel form dz[z] without a load
     T dz_scale;      // sigma_max dt / (2 npml^2): d_z(z) = dz_scale * dist(z)^2
@@ -143,8 +143,9 @@ struct PmlArgs {
     T *q_out;         // compact forward term of this step (phase 3 adds the border term), or nullptr
     T *psi[3], *zeta[3];    // memory variables per axis (z, y, x), compact over that axis' border; [1] unused in 2-D
     const T *a[3], *b[3];   // 1-D coefficients per axis
-    T ck[5];          // second-difference weights / h^2 (ck[0] = centre)
-    T dk[5];          // first-difference weights / h, k = 1..r
+    T ck[5];          // second-difference weights a_k / a_1 (ck[0] = centre): C carries a_1 / h^2
+    T dk[5];          // first-difference weights d_k / h, k = 1..r: D of a memory variable
+    T dk1[5];         // d_k h / a_1: D of the field inside the memory-variable recursions (memory variables x h^2 / a_1)
     int npml;
 };
 // phase 1, 2: advance the memory variables (before the step kernel); 3: add their term to u' (after it)
@@ -182,10 +183,21 @@ struct Fused2dArgs {
     float *rec_out;                     // (nt, nrec), row n written by step n
     float rec_scale;
     int nrec;
+    // convolutional PML inside the launch (fwi_fused2d_pml.hip; npml = 0: off): memory variables of the z (index 0)
+    // and x (index 1) border in the layout of the slab kernels (fwi_pml.hip), 1-D coefficients, first-difference
+    // weights (dk: of a memory variable, dk1: of the field, see PmlArgs) and the direction of the recursion
+    int pml_npml, pml_rev;
+    float *pml_psi[2], *pml_zeta[2];
+    const float *pml_a[2], *pml_b[2];
+    float pml_dk[5], pml_dk1[5];
 };
 
 int fused2d_num_tiles(const GridDesc &g);
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
+// True when the fused kernel can carry the CPML of this grid: every border cell a tile sees lies deep inside that
+// tile's extended region or against the outside of the grid (conditions at fused2d_cpml_supported).
+bool fused2d_cpml_supported(const GridDesc &g, int npml);
+hipError_t launch_fused2d_cpml(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
 
 // ---- 3-D temporal blocking (fwi_pair3d.hip): two time steps per pass, fp32, forward sweeps without imaging ----
 constexpr int PAIR3D_TY = 8;   // interior rows (= waves) per workgroup

@@ -208,16 +208,21 @@ __device__ __forceinline__ void stv_stream(T *p, const vec<T> &f) {
     __builtin_nontemporal_store(v, reinterpret_cast<nt_t *>(p));
 }
 // Forward-term store in bf16 (fwi_config.store_dtype): 4 values = 8 bytes per lane, round to nearest even on the
-// way out, exact on the way in.  bf16 keeps fp32's exponent, so the term needs no scaling.
+// way out, exact on the way in.  bf16 keeps fp32's exponent, so the term needs no scaling.  The conversion is the
+// plain cast (v_cvt_pk_bf16_f32): the integer-rounding form (u + 0x7fff + lsb) >> 16 turns some NaNs into 0 or
+// infinity (MI355X_MICROARCH.md, correctness boundaries), which would launder a blown-up forward run into a
+// finite-looking gradient; the cast keeps every NaN a NaN and rounds finite values identically.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void st_bf16x4_stream(void *base, int64_t elem, const vec<float> &q) {
     u32x2 w;
-    w[0] = bf16_rne(q.v[0]) | (bf16_rne(q.v[1]) << 16);
-    w[1] = bf16_rne(q.v[2]) | (bf16_rne(q.v[3]) << 16);
+    w[0] = bf16_pack2(q.v[0], q.v[1]);
+    w[1] = bf16_pack2(q.v[2], q.v[3]);
     __builtin_nontemporal_store(w, reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(base) + elem));
 }
 __device__ __forceinline__ vec<float> ld_bf16x4_stream(const void *base, int64_t elem) {

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
             for (int k = 1; k <= R; ++k) {
                 const V up = U(k), um = U(-k);
 #pragma unroll
-                for (int q = 0; q < VL; ++q) du.v[q] = fma(p.dk[k], up.v[q] - um.v[q], du.v[q]);
+                for (int q = 0; q < VL; ++q) du.v[q] = fma(p.dk1[k], up.v[q] - um.v[q], du.v[q]);
             }
 #pragma unroll
             for (int q = 0; q < VL; ++q) out.v[q] = fma(v.b[i], out.v[q], v.a[i] * du.v[q]);
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void pml_kernel(PmlArgs<T> p, GridDesc g) {
                 const V zp = aux_at<T, VL>(zet, v, abase, ip), zm = aux_at<T, VL>(zet, v, abase, im);
 #pragma unroll
                 for (int q = 0; q < VL; ++q) {
-                    du.v[q] = fma(p.dk[k], up.v[q] - um.v[q], du.v[q]);
-                    da.v[q] = fma(p.dk[k], ap * zp.v[q] - am * zm.v[q], da.v[q]);
+                    du.v[q] = fma(p.dk1[k], up.v[q] - um.v[q], du.v[q]);
+                    da.v[q] = fma(p.dk1[k], ap * zp.v[q] - am * zm.v[q], da.v[q]);
                 }
             }
             V ps = ldn<T, VL>(psi + ai);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
             if (!REV) {
                 float du = 0.f;
 #pragma unroll
-                for (int k = 1; k <= R; ++k) du = fmaf(p.dk[k], X[4 + q + k] - X[4 + q - k], du);
+                for (int k = 1; k <= R; ++k) du = fmaf(p.dk1[k], X[4 + q + k] - X[4 + q - k], du);
                 out.v[q] = fmaf(B[i + q], out.v[q], A[i + q] * du);
             } else {
                 out.v[q] = fmaf(B[i + q], out.v[q], X[4 + q]);
@@ -341,9 +341,9 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
             float du = 0.f, dy = 0.f, e2 = p.ck[0] * X[4 + q];
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
-                du = fmaf(p.dk[k], X[4 + q + k] - X[4 + q - k], du);
+                du = fmaf(p.dk1[k], X[4 + q + k] - X[4 + q - k], du);
                 e2 = fmaf(p.ck[k], X[4 + q + k] + X[4 + q - k], e2);
-                dy = fmaf(p.dk[k], Y[4 + q + k] - Y[4 + q - k], dy);
+                dy = fmaf(REV ? p.dk1[k] : p.dk[k], Y[4 + q + k] - Y[4 + q - k], dy);
             }
             out.v[q] = REV ? B[i + q] * out.v[q] - du - dy : fmaf(B[i + q], out.v[q], A[i + q] * (e2 + dy));
         }

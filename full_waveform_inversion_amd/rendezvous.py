@@ -8,9 +8,15 @@ to everyone, a barrier, and a reduction of a few doubles -- the role the referen
 ``multiprocessing.Pipe`` gather plays (full_waveform_inversion.py:816-848).
 
 Topology: a star.  Rank 0 listens, every other rank connects and says who it is.  MASTER_PORT itself may
-be held by the launcher (torchrun's agent keeps its own store there), so rank 0 takes the first free port
-of ``MASTER_PORT + 1 .. + 64`` and the other ranks probe that range; the hello carries MASTER_PORT and the
-world size as a job token, so a listener of another job on a neighbouring port is skipped rather than joined.
+be held by the launcher (torchrun's agent keeps its own store there), and jobs on one node are commonly
+given ADJACENT MASTER_PORTs, so the control port is looked for well away from it: rank 0 takes the first
+free port of a 64-port window derived from MASTER_PORT (``control_port_base``: 20000 + a multiple of 64
+below 65536, so that neighbouring MASTER_PORTs get disjoint windows and none of them contains a
+MASTER_PORT of the usual 29500+ range), and the other ranks probe that window.  ``FWI_RDZV_PORT`` names
+the control port explicitly (a window of one).  The hello carries MASTER_PORT and the world size as a job
+token, so a listener of another job that landed in the same window is skipped rather than joined.
+Messages are capped at 64 MiB (``MAX_MESSAGE_BYTES``): nothing the control plane carries comes near it,
+and a peer that announces more is a protocol error, not an allocation.
 """
 from __future__ import annotations
 
@@ -23,6 +29,12 @@ _MAGIC = b"FWIRDZV1"
 _PORT_SPAN = 64
 _HELLO = struct.Struct("!8sIII")   # magic, token (MASTER_PORT), world, rank
 _LEN = struct.Struct("!Q")
+MAX_MESSAGE_BYTES = 64 << 20
+
+
+def control_port_base(master_port):
+    """First port of the 64-port control window of the job whose launcher holds ``master_port``."""
+    return 20000 + ((int(master_port) * 64) % (9472 - _PORT_SPAN))  # 20000 .. 29407: below the 29500+ launchers
 
 
 class RendezvousError(RuntimeError):
@@ -45,6 +57,8 @@ def _send_msg(sock, payload):
 
 def _recv_msg(sock):
     (n,) = _LEN.unpack(_recv_exact(sock, _LEN.size))
+    if n > MAX_MESSAGE_BYTES:
+        raise RendezvousError("peer announced a %d-byte control message (limit %d)" % (n, MAX_MESSAGE_BYTES))
     return _recv_exact(sock, n)
 
 
@@ -62,6 +76,9 @@ class Rendezvous:
         self._peers = []      # rank 0: sockets of ranks 1 .. world-1, by rank
         self._up = None       # other ranks: socket to rank 0
         self._listener = None
+        explicit = os.environ.get("FWI_RDZV_PORT")
+        self._ports = [int(explicit)] if explicit else list(range(control_port_base(self.port),
+                                                                   control_port_base(self.port) + _PORT_SPAN))
         if self.world > 1:
             if self.rank == 0:
                 self._serve()
@@ -77,7 +94,7 @@ class Rendezvous:
     # -- set-up -------------------------------------------------------------------------------------
     def _serve(self):
         ls = None
-        for p in range(self.port + 1, self.port + 1 + _PORT_SPAN):
+        for p in self._ports:
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
@@ -88,7 +105,7 @@ class Rendezvous:
             except OSError:
                 s.close()
         if ls is None:
-            raise RendezvousError("no free control port in %d..%d" % (self.port + 1, self.port + _PORT_SPAN))
+            raise RendezvousError("no free control port in %d..%d" % (self._ports[0], self._ports[-1]))
         self._listener = ls
         peers = {}
         deadline = time.monotonic() + self.timeout
@@ -120,7 +137,7 @@ class Rendezvous:
         deadline = time.monotonic() + self.timeout
         hello = _HELLO.pack(_MAGIC, self.port, self.world, self.rank)
         while time.monotonic() < deadline:
-            for p in range(self.port + 1, self.port + 1 + _PORT_SPAN):
+            for p in self._ports:
                 try:
                     s = socket.create_connection((self.addr, p), timeout=2.0)
                 except OSError:
@@ -138,7 +155,7 @@ class Rendezvous:
                 s.close()
             time.sleep(0.05)
         raise RendezvousError("rank %d found no rank 0 on %s:%d..%d within %.0f s"
-                              % (self.rank, self.addr, self.port + 1, self.port + _PORT_SPAN, self.timeout))
+                              % (self.rank, self.addr, self._ports[0], self._ports[-1], self.timeout))
 
     def set_timeout(self, seconds):
         """Bound how long a collective waits for a peer from now on (an optional phase of a job can then fail

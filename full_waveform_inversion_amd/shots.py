@@ -211,11 +211,16 @@ def model_data(engine, model, shots, exchange=None):
     return shots
 
 
-def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", objective=None):
+def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", objective=None, device_l2=True):
     """J = sum_shots objective(F_s(model), d_obs,s) and dJ/dmodel, summed over all ranks.
 
     ``objective(d_syn, d_obs) -> (J, dJ/dd_syn)``; default least squares 1/2 ||d_syn - d_obs||^2
     (see objectives.py for the reference's similarity measures as misfits).
+
+    ``device_l2`` (least squares only): form the residual and J on the device (``fwi_misfit_l2``) -- in the
+    engine's dtype, i.e. with an fp32 engine ``d_obs`` is rounded to fp32 before the subtraction, which puts
+    ~6e-8 |d| / |r| of relative noise on J and on the residual (visible to a line search only once |r| / |d|
+    approaches 1e-6).  ``device_l2=False`` keeps the residual in fp64 on the host, ``d_obs`` exact.
     """
     from .objectives import l2
     objective = objective or l2
@@ -223,11 +228,11 @@ def misfit_and_gradient(engine, model, shots, exchange=None, wrt="velocity", obj
     for e in _engines(engine):
         e.set_model(model)
         e.reset_gradient()
-    misfit = _sweep_shots(engine, shots, ex, objective)
+    misfit = _sweep_shots(engine, shots, ex, objective, device_l2)
     return ex.reduce(_engines(engine)[0], misfit, wrt)[::-1]
 
 
-def _sweep_shots(engine, shots, ex, objective):
+def _sweep_shots(engine, shots, ex, objective, device_l2=True):
     """forward + adjoint of this rank's shots; returns the misfit, gradients summed into the
     (primary) engine's accumulator."""
     from .objectives import l2
@@ -237,7 +242,7 @@ def _sweep_shots(engine, shots, ex, objective):
         if s.d_obs is None:
             raise ValueError("shot %d has no observed data on rank %d" % (i, ex.rank))
         d = s.forward(e, save=True)
-        if objective is l2 and hasattr(e, "misfit_l2") and (s.rec_spread is None or s._on_device(e)):
+        if device_l2 and objective is l2 and hasattr(e, "misfit_l2") and (s.rec_spread is None or s._on_device(e)):
             # least squares: residual and misfit are formed on the device (per node, or per off-grid point)
             j = e.misfit_l2(s.d_obs)
             e.adjoint(None)
@@ -256,7 +261,7 @@ def _sweep_shots(engine, shots, ex, objective):
 
 
 def misfit_and_gradient_device(engine, model_slot, grad_slot, shots, exchange=None, wrt="velocity",
-                               objective=None):
+                               objective=None, device_l2=True):
     """Like :func:`misfit_and_gradient`, with the model read from and the gradient written to
     device-resident vectors (``Engine.vec_*``): no model-sized array crosses PCIe."""
     from .objectives import l2
@@ -270,7 +275,7 @@ def misfit_and_gradient_device(engine, model_slot, grad_slot, shots, exchange=No
             e.set_model(model)
     for e in engs:
         e.reset_gradient()
-    misfit = _sweep_shots(engine, shots, ex, objective)
+    misfit = _sweep_shots(engine, shots, ex, objective, device_l2)
     misfit = ex.reduce_device(engs[0], misfit)
     engs[0].gradient_vec(grad_slot, wrt)
     return misfit

@@ -31,6 +31,14 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((70, 90), 8, 8, 40.0, "float32", TOL32, "step2d_tile", {}),          # 2-D: one step per launch with the CPML
     ((70, 91), 2, 7, 0.0, "float32", TOL32, "step2d_tile", {}),
     ((70, 90), 8, 8, 40.0, "float64", TOL64, "step_point", {}),
+    # grids the fused 2-D kernel takes WITH the border recursion inside the launch (fused2d_cpml_supported): 70 steps
+    # = 68 in 4-step launches + 2 through the slab path, on the same memory variables
+    ((192, 256), 8, 40, 40.0, "float32", TOL32, "step2d_fused", {}),            # cfg2's border width, 48-cell images
+    ((176, 240), 8, 16, 30.0, "float32", TOL32, "step2d_fused", {}),            # last tiles 48 wide
+    ((150, 216), 8, 6, 0.0, "float32", TOL32, "step2d_fused", {}),              # high borders off the 16-byte groups,
+                                                                                # last tiles exactly npml + 16 wide
+    ((192, 256), 8, 24, 40.0, "float32", TOL32, "step2d_fused", {"ckpt_interval": 16}),
+    ((149, 216), 8, 6, 0.0, "float32", TOL32, "step2d_tile", {}),               # last tile one cell too narrow: slab path
 ]
 
 
@@ -94,6 +102,31 @@ def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
     ref = run(big, "sponge", 0)
     e_sponge, e_cpml = rel(run(n, "sponge", npml), ref), rel(run(n, "cpml", npml), ref)
     assert e_sponge > 0.05 and e_cpml < 2e-3
+
+
+@pytest.mark.parametrize("shape,npml,nt", [((192, 256), 40, 72), ((150, 216), 6, 41)])
+def test_cpml_inside_the_fused_launch_equals_the_slab_path(gpu, monkeypatch, shape, npml, nt):
+    """The same shot through step2d_fused with the border recursion inside the launch and through step2d_tile +
+    slab kernels (FWI_NO_FUSED2D_CPML=1): seismograms, F^T r and gradient agree to fp32 round-off."""
+    rng = np.random.default_rng(5)
+    c = (1800.0 + 900.0 * rng.random(shape)).astype(np.float32)
+    h, order = 10.0, 8
+    dt = 0.7 * fo.cfl_dt(float(c.max()), h, 2, order)
+    src = np.array([[3, shape[1] // 2], [shape[0] // 2, 2]])
+    rec = np.array([[1, 1], [shape[0] - 1, shape[1] - 1], [shape[0] // 2, shape[1] // 3], [2, shape[1] - 3]])
+    wav = np.stack([fo.ricker(nt, dt, 0.1 / dt / 8), fo.ricker(nt, dt, 0.1 / dt / 5)], 1).astype(np.float32)
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("FWI_NO_FUSED2D_CPML", env)
+        with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=900.0, abc="cpml", pml_alpha_max=30.0) as e:
+            d = e.forward(c, (src, wav), rec, save=True)
+            kern = e.kernel_name
+            a = e.adjoint(d)
+            out.append((kern, d, a, e.gradient()))
+    assert out[0][0] == "step2d_fused" and out[1][0] == "step2d_tile"
+    for i in (1, 2, 3):
+        assert rel(out[0][i], out[1][i]) < 2e-6, (i, rel(out[0][i], out[1][i]))
 
 
 def test_cpml_configuration_errors(gpu):

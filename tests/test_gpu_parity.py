@@ -287,6 +287,36 @@ def test_end_to_end_fp64_engine_flat_1e5(gpu, maker, scale, nshots):
     assert rel(g, g_ref) < 1e-5
 
 
+@pytest.mark.parametrize("maker,scale", [(workloads.cfg2, 0.5), (workloads.cfg2, 1.0), (workloads.cfg4, 0.5),
+                                         (workloads.cfg5, 0.25), (workloads.cfg5, 0.5)])
+def test_end_to_end_fp32_increment_form_flat_1e5(gpu, maker, scale):
+    """north_star's bar on an fp32 PRODUCTION mode: update_form="increment".  Observed data are
+    the shared input, each path forms its OWN residual, and seismograms, misfit and gradient agree with the oracle
+    to a FLAT 1e-5 -- every BASELINE config family, configs[1] at full size.  What made this possible in round 3 is
+    the normalisation of the star weights (fwi_api.hip base_args): the rounded a_k / h^2 were a systematic operator
+    perturbation that dominated the fp32 error (profiles/r03_parity.json; e.g. 1024^2 x 2000: 2.0e-5 -> 4.5e-6)."""
+    w = maker(scale)
+    wav = w.wavelet(np.float64)
+    src = w.src_idx[:1]
+    c0 = w.c_init if w.c_init is not None else w.c * (1.0 + 0.03 * np.sin(np.indices(w.shape).sum(0) / 9.0))
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    d_obs = p.forward(src, wav, w.rec_idx, save=False)
+    p0 = CPropagator(c0, w.h, w.dt, w.order, w.npml, sigma_max=p.sigma_max)
+    d0 = p0.forward(src, wav, w.rec_idx)
+    r = d0 - d_obs
+    p0.adjoint(r)
+    g0, J0 = p0.gradient(), 0.5 * float(np.sum(r * r))
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max,
+                update_form="increment") as e:
+        dg = e.forward(c0, (src, wav), w.rec_idx, save=True)
+        rg = dg.astype(np.float64) - d_obs
+        e.adjoint(rg)
+        gg = e.gradient()
+    assert rel(dg, d0) < 1e-5
+    assert abs(0.5 * float(np.sum(rg * rg)) - J0) < 1e-5 * J0
+    assert rel(gg, g0) < 1e-5, rel(gg, g0)
+
+
 # ---------------------------------------------------------------------------
 # edge cases and error behaviour
 # ---------------------------------------------------------------------------

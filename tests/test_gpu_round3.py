@@ -1,0 +1,59 @@
+"""Round-3 GPU tests: call-order state, NaN-preserving bf16 store."""
+import numpy as np
+import pytest
+
+from full_waveform_inversion_amd import Engine, FwiError
+from oracle import fwi_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_shot(shape, nt=40, order=8):
+    rng = np.random.default_rng(3)
+    c = 2000.0 + 500.0 * rng.random(shape)
+    h = 10.0
+    dt = 0.7 * fo.cfl_dt(c.max(), h, len(shape), order)
+    src = np.array([[s // 2 for s in shape]])
+    rec = np.array([[s // 3 for s in shape], [2 * s // 3 for s in shape]])
+    wav = fo.ricker(nt, dt, 0.1 / dt / 8).astype(np.float32)
+    return c, h, dt, src, rec, wav
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 44), (70, 90)])
+def test_misfit_l2_after_an_adjoint_is_a_state_error(gpu, shape):
+    """fwi_adjoint records its source-side series into the buffer the synthetics lived in: a misfit asked for after
+    it must fail (FWI_ESTATE), not return a J built from adjoint data; a new forward makes it valid again."""
+    c, h, dt, src, rec, wav = _small_shot(shape)
+    with Engine(shape, h, dt, len(wav)) as e:
+        d = e.forward(c, (src, wav), rec, save=False)
+        J = e.misfit_l2(np.zeros_like(d))
+        assert abs(J - 0.5 * float(np.sum(d.astype(np.float64) ** 2))) <= 1e-5 * J
+        e.adjoint(d, image=False)
+        with pytest.raises(FwiError) as ei:
+            e.misfit_l2(np.zeros_like(d))
+        assert ei.value.code == 3
+        e.forward(None, (src, wav), rec, save=False)
+        assert abs(e.misfit_l2(np.zeros_like(d)) - J) <= 1e-6 * J
+
+
+def test_bf16_store_keeps_a_nan_a_nan(gpu):
+    """A forward run that blows up (dt twice the CFL limit) must not come out of the bf16 forward-term store as a
+    finite-looking gradient: the conversion is the plain cast (v_cvt_pk_bf16_f32), which keeps every NaN."""
+    shape = (40, 36, 64)
+    c, h, dt, src, rec, wav = _small_shot(shape, nt=400)
+    dt_bad = 2.0 * fo.cfl_dt(c.max(), h, 3, 8)
+    with Engine(shape, h, dt_bad, len(wav), store_dtype="bf16") as e:
+        d = e.forward(c, (src, wav), rec, save=True)
+        assert not np.isfinite(d).all()          # the run did blow up
+        e.adjoint(np.ones_like(d) * 1e-3)
+        g = e.gradient()
+    assert not np.isfinite(g).all()
+    # and a healthy run through the same store stays finite and close to the native store's gradient
+    with Engine(shape, h, dt, 60, store_dtype="bf16") as e, Engine(shape, h, dt, 60) as e2:
+        out = []
+        for eng in (e, e2):
+            dd = eng.forward(c, (src, wav[:60]), rec, save=True)
+            eng.adjoint(dd)
+            out.append(eng.gradient())
+    assert np.isfinite(out[0]).all()
+    assert np.linalg.norm(out[0] - out[1]) < 2e-2 * np.linalg.norm(out[1])

@@ -97,15 +97,16 @@ def test_control_plane_under_torch_distributed_run(tmp_path):
     assert open(out + ".rank0").read() == "ok 0 2" and open(out + ".rank1").read() == "ok 1 2"
 
 
-def test_control_plane_skips_a_foreign_listener_and_times_out_alone():
-    """A rank 0 of ANOTHER job (different MASTER_PORT token) on a neighbouring port is not joined; a rank whose
+def test_control_plane_skips_a_foreign_listener_and_times_out_alone(monkeypatch):
+    """A rank 0 of ANOTHER job (different MASTER_PORT token) on the same control port is not joined; a rank whose
     rank 0 never appears gives up with an error instead of hanging."""
     import threading
     from full_waveform_inversion_amd.rendezvous import Rendezvous, RendezvousError
     port = _free_port()
+    monkeypatch.setenv("FWI_RDZV_PORT", str(_free_port()))  # both jobs are pointed at ONE explicit control port
     res = {}
 
-    def other_job():  # listens on port + 2 (its own MASTER_PORT is port + 1), waits for a peer that never comes
+    def other_job():  # listens on the control port (its own MASTER_PORT is port + 1), waits for a peer that never comes
         try:
             Rendezvous(0, 2, "127.0.0.1", port + 1, timeout=3.0)
         except RendezvousError as ex:
@@ -114,11 +115,31 @@ def test_control_plane_skips_a_foreign_listener_and_times_out_alone():
     t = threading.Thread(target=other_job)
     t.start()
     with pytest.raises(RendezvousError, match="found no rank 0"):
-        Rendezvous(1, 2, "127.0.0.1", port, timeout=1.5)  # probes port + 1 .. : meets the other job, is refused
+        Rendezvous(1, 2, "127.0.0.1", port, timeout=1.5)  # meets the other job's listener, is refused
     t.join()
     assert "only 1 of 2 ranks joined" in res["other"]
     with pytest.raises(ValueError):
         Rendezvous(2, 2)
+
+
+def test_control_ports_keep_away_from_master_ports_and_messages_are_capped():
+    """jobs on one node get adjacent MASTER_PORTs -- their control windows must be disjoint and must
+    not contain a launcher port; a peer that announces an absurd message length is an error, not an allocation."""
+    import struct
+    from full_waveform_inversion_amd import rendezvous as rz
+    for mp in (29500, 29501, 29555, 12345, 65000):
+        a, b = rz.control_port_base(mp), rz.control_port_base(mp + 1)
+        assert 20000 <= a and a + 64 <= 29500 and abs(a - b) >= 64, (mp, a, b)
+    s1, s2 = socket.socketpair()
+    try:
+        s1.sendall(struct.pack("!Q", rz.MAX_MESSAGE_BYTES + 1))
+        with pytest.raises(rz.RendezvousError, match="limit"):
+            rz._recv_msg(s2)
+        rz._send_msg(s1, b"abc")
+        assert rz._recv_msg(s2) == b"abc"
+    finally:
+        s1.close()
+        s2.close()
 
 
 def test_control_plane_bounded_wait_for_an_optional_phase():
