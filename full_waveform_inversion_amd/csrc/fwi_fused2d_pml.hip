@@ -56,6 +56,11 @@ bool fused2d_cpml_supported(const GridDesc &g, int npml) {
 }
 
 // NPB: border width the memory-variable images are sized for (npml <= NPB).  REV: the adjoint recursion.
+// Diagnostic builds only (-DFWI_CPML_ABLATE=bits, timing A/B; results are wrong): 1 = no neighbour pass, 2 = no border
+// term in the update, 4 = constant C instead of the global load.
+#ifndef FWI_CPML_ABLATE
+#define FWI_CPML_ABLATE 0
+#endif
 template <int R, int KS, int FT, int NPB, bool SAVE_Q, bool IMAGE, bool REV>
 __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDesc g) {
     constexpr int FNT = 1024;
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
     __shared__ q4 zz[NPB][E4];  // zeta (adjoint: zt) of the z border
     __shared__ q4 px[E][NXG];   // psi / pt of the x border: image group gx <-> extended group pbx / 4 + gx
     __shared__ q4 zx[E][NXG];   // zeta / zt of the x border
-    __shared__ float az[E], bz[E], ax[E], bx[E];  // a, b by extended row / column; 0 off the border and off the grid
+    __shared__ float az[E], bz[E];             // a, b by extended row; 0 off the border and off the grid
+    __shared__ __align__(16) float ax[E], bx[E];  // ... by extended column (read one 16-byte group at a time)
 
     const int tid = threadIdx.x;
     const int ntx = (g.nx + FT - 1) / FT;
@@ -169,6 +175,8 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
     const int s0 = a.inj_start ? a.inj_start[tile] : 0, s1 = a.inj_start ? a.inj_start[tile + 1] : 0;
     const int r0 = a.rec_start ? a.rec_start[tile] : 0, r1 = a.rec_start ? a.rec_start[tile + 1] : 0;
     const int pg = pbx >> 2;  // first extended group of the x images (when pbx >= 0)
+    // groups of the x images that hold border cells (the high border may start up to 3 cells into its first group)
+    const int ngx = pbx < 0 ? 0 : (((x0 < npml) ? 0 : (g.nx - npml - x0) - pbx) + npml + 3) >> 2;
 
     // 12 consecutive values around group l4 of a row: [l4 - 1][l4][l4 + 1]
     auto window = [&](const q4 *row, int l4, float *X) __attribute__((always_inline)) {
@@ -185,13 +193,13 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int gg = gx - 1 + t;
-            q4 w = {{0.f, 0.f, 0.f, 0.f}};
-            if (gg >= 0 && gg < NXG) w = row[gg];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int lx = 4 * (l4 - 1 + t) + j;
-                X[4 * t + j] = times_a ? ((lx >= 0 && lx < E) ? ax[lx] : 0.f) * w.v[j] : w.v[j];
+            q4 w = {{0.f, 0.f, 0.f, 0.f}}, c = {{1.f, 1.f, 1.f, 1.f}};
+            if (gg >= 0 && gg < NXG) {
+                w = row[gg];
+                if (times_a) c = reinterpret_cast<const q4 *>(ax)[l4 - 1 + t];  // (an image group is inside the region)
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[4 * t + j] = times_a ? c.v[j] * w.v[j] : w.v[j];
         }
     };
 
@@ -215,11 +223,17 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
                     qv[i] = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(qslot + (int64_t)z * g.cx + x));
             }
         }
-        // ---- memory variables that the update reads at NEIGHBOURING cells: psi' (forward); zt', then pt' (adjoint) ----
-        if (!REV) {
+        // ---- memory variables that the update reads at NEIGHBOURING cells: psi' (forward); zt', then pt' (adjoint).
+        // Only over the transverse range this sub-step still updates: columns [lo, hi) of the z images, rows [lo, hi)
+        // of the x images (one item per thread at npml = 40: 40 x 22 and 88 x 10 in the first sub-step) ----
+        constexpr int c4 = lo / 4, nc4 = (hi - lo) / 4, nrw = hi - lo;
+        static_assert(lo % 4 == 0 && hi % 4 == 0, "active columns are whole groups");
+        if (FWI_CPML_ABLATE & 1) {
+            __syncthreads();
+        } else if (!REV) {
             if (pbz >= 0) {
-                for (int i = tid; i < npml * E4; i += FNT) {
-                    const int r = i / E4, l4 = i % E4, lz = pbz + r;
+                for (int i = tid; i < npml * nc4; i += FNT) {
+                    const int r = i / nc4, l4 = c4 + i % nc4, lz = pbz + r;
                     q4 du = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                     for (int k = 1; k <= R; ++k) {
@@ -235,17 +249,18 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
                 }
             }
             if (pbx >= 0) {
-                for (int i = tid; i < E * NXG; i += FNT) {
-                    const int lz = i / NXG, gx = i % NXG, l4 = pg + gx;
+                for (int i = tid; i < nrw * ngx; i += FNT) {
+                    const int lz = lo + i / ngx, gx = i % ngx, l4 = pg + gx;
                     float X[12];
                     window(cur[lz], l4, X);
                     q4 p = px[lz][gx];
+                    const q4 a4 = reinterpret_cast<const q4 *>(ax)[l4], b4 = reinterpret_cast<const q4 *>(bx)[l4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float du = 0.f;
 #pragma unroll
                         for (int k = 1; k <= R; ++k) du = fmaf(a.pml_dk1[k], X[4 + j + k] - X[4 + j - k], du);
-                        p.v[j] = fmaf(bx[4 * l4 + j], p.v[j], ax[4 * l4 + j] * du);
+                        p.v[j] = fmaf(b4.v[j], p.v[j], a4.v[j] * du);
                     }
                     px[lz][gx] = p;
                 }
@@ -253,8 +268,8 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
             __syncthreads();
         } else {
             if (pbz >= 0) {
-                for (int i = tid; i < npml * E4; i += FNT) {
-                    const int r = i / E4, l4 = i % E4, lz = pbz + r;
+                for (int i = tid; i < npml * nc4; i += FNT) {
+                    const int r = i / nc4, l4 = c4 + i % nc4, lz = pbz + r;
                     const q4 u = cur[lz][l4];
                     q4 z = zz[r][l4];
                     const float bv = bz[lz];
@@ -264,19 +279,20 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
                 }
             }
             if (pbx >= 0) {
-                for (int i = tid; i < E * NXG; i += FNT) {
-                    const int lz = i / NXG, gx = i % NXG, l4 = pg + gx;
+                for (int i = tid; i < nrw * ngx; i += FNT) {
+                    const int lz = lo + i / ngx, gx = i % ngx, l4 = pg + gx;
                     const q4 u = cur[lz][l4];
                     q4 z = zx[lz][gx];
+                    const q4 b4 = reinterpret_cast<const q4 *>(bx)[l4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z.v[j] = fmaf(bx[4 * l4 + j], z.v[j], u.v[j]);
+                    for (int j = 0; j < 4; ++j) z.v[j] = fmaf(b4.v[j], z.v[j], u.v[j]);
                     zx[lz][gx] = z;
                 }
             }
             __syncthreads();
             if (pbz >= 0) {
-                for (int i = tid; i < npml * E4; i += FNT) {
-                    const int r = i / E4, l4 = i % E4, lz = pbz + r;
+                for (int i = tid; i < npml * nc4; i += FNT) {
+                    const int r = i / nc4, l4 = c4 + i % nc4, lz = pbz + r;
                     q4 d = {{0.f, 0.f, 0.f, 0.f}};  // D mu + D (a zt')
 #pragma unroll
                     for (int k = 1; k <= R; ++k) {
@@ -297,19 +313,20 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
                 }
             }
             if (pbx >= 0) {
-                for (int i = tid; i < E * NXG; i += FNT) {
-                    const int lz = i / NXG, gx = i % NXG, l4 = pg + gx;
+                for (int i = tid; i < nrw * ngx; i += FNT) {
+                    const int lz = lo + i / ngx, gx = i % ngx, l4 = pg + gx;
                     float X[12], A[12];
                     window(cur[lz], l4, X);
                     xwindow(zx[lz], gx, true, l4, A);
                     q4 p = px[lz][gx];
+                    const q4 b4 = reinterpret_cast<const q4 *>(bx)[l4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float d = 0.f;
 #pragma unroll
                         for (int k = 1; k <= R; ++k)
                             d = fmaf(a.pml_dk1[k], (X[4 + j + k] - X[4 + j - k]) + (A[4 + j + k] - A[4 + j - k]), d);
-                        p.v[j] = bx[4 * l4 + j] * p.v[j] - d;
+                        p.v[j] = b4.v[j] * p.v[j] - d;
                     }
                     px[lz][gx] = p;
                 }
@@ -324,12 +341,13 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
             const int lz = lo + gi / w4, l4 = gi % w4;
             // C of this group from global memory (zero halo outside the grid), in flight under the LDS reads below
             const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
-            const q4 Cc = *reinterpret_cast<const q4 *>(a.C + g.off0 + (int64_t)zc * g.sz + xc);
+            const q4 Cc = (FWI_CPML_ABLATE & 4) ? q4{{.1f, .1f, .1f, .1f}}
+                                                : *reinterpret_cast<const q4 *>(a.C + g.off0 + (int64_t)zc * g.sz + xc);
             q4 term = {{0.f, 0.f, 0.f, 0.f}};
             const int rz = lz - pbz;
-            const bool zreach = pbz >= 0 && rz >= -R && rz < npml + R;  // rows the z border reaches (D: +- R)
+            const bool zreach = !(FWI_CPML_ABLATE & 2) && pbz >= 0 && rz >= -R && rz < npml + R;  // rows the z border reaches (D: +- R)
             const int gx = l4 - pg;
-            const bool xreach = pbx >= 0 && gx >= -1 && gx <= NXG;        // groups the x border reaches
+            const bool xreach = !(FWI_CPML_ABLATE & 2) && pbx >= 0 && gx >= -1 && gx <= ngx;      // groups the x border reaches
             if (REV) {
                 // the adjoint term needs no second difference of the field: formed first, while little else is live
                 if (zreach) {
@@ -422,12 +440,13 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
                     const bool own = gx >= 0 && gx < NXG;
                     q4 z = {{0.f, 0.f, 0.f, 0.f}};
                     if (own) z = zx[lz][gx];
+                    const q4 a4 = reinterpret_cast<const q4 *>(ax)[l4], b4 = reinterpret_cast<const q4 *>(bx)[l4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float dp = 0.f;
 #pragma unroll
                         for (int k = 1; k <= R; ++k) dp = fmaf(a.pml_dk[k], P[4 + j + k] - P[4 + j - k], dp);
-                        z.v[j] = fmaf(bx[4 * l4 + j], z.v[j], ax[4 * l4 + j] * (ex.v[j] + dp));  // (a = b = 0 off the border)
+                        z.v[j] = fmaf(b4.v[j], z.v[j], a4.v[j] * (ex.v[j] + dp));  // (a = b = 0 off the border)
                         term.v[j] += dp + z.v[j];
                     }
                     if (own) zx[lz][gx] = z;

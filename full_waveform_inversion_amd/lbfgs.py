@@ -6,11 +6,37 @@ iterations on the all-reduced gradient, which is what this drives.
 """
 from __future__ import annotations
 
+import json
+import os
+
 import numpy as np
 
 
+def save_state(path, it, x, f, g, S, Y, log, evals):
+    """Optimiser state after iteration ``it`` (SURVEY.md s.5 "checkpoint / resume": "optimiser state save per L-BFGS
+    iteration"): model, misfit, gradient, the curvature pairs oldest first, the log.  Written to a temporary file and
+    renamed, so an interrupted run never leaves a torn file behind."""
+    tmp = "%s.tmp.%d.npz" % (path, os.getpid())
+    arrays = {"x": np.asarray(x), "g": np.asarray(g)}
+    for i, (s, y) in enumerate(zip(S, Y)):
+        arrays["s%d" % i] = np.asarray(s)
+        arrays["y%d" % i] = np.asarray(y)
+    np.savez(tmp, it=np.int64(it), f=np.float64(f), evals=np.int64(evals), npairs=np.int64(len(S)),
+             log=np.frombuffer(json.dumps(log).encode(), np.uint8), **arrays)
+    os.replace(tmp, path)
+
+
+def load_state(path):
+    """The dict :func:`save_state` wrote: ``it, f, evals, x, g, S, Y, log``."""
+    with np.load(path) as z:
+        n = int(z["npairs"])
+        return {"it": int(z["it"]), "f": float(z["f"]), "evals": int(z["evals"]), "x": z["x"].copy(), "g": z["g"].copy(),
+                "S": [z["s%d" % i].copy() for i in range(n)], "Y": [z["y%d" % i].copy() for i in range(n)],
+                "log": json.loads(bytes(z["log"]).decode())}
+
+
 def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, c1=1e-4, max_ls=8,
-          gtol=0.0, callback=None, c2=0.9):
+          gtol=0.0, callback=None, c2=0.9, checkpoint=None, resume=None):
     """Minimise ``f`` given ``fg(x) -> (f, g)``.
 
     Line search: backtracking (safeguarded quadratic interpolation) until the Armijo condition holds; while no backtracking was needed and the slope
@@ -21,6 +47,11 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
     ``first_step``: largest change of any component in the first trial step (the gradient of
     an FWI misfit has no natural scale).  ``dot(a, b)``: inner product (pass ``Engine.dot``
     for the GPU wave-shuffle reduction).  Returns ``(x, f, log)``.
+
+    ``checkpoint``: path of a state file rewritten after every completed iteration (:func:`save_state`).
+    ``resume``: such a path (or the dict of :func:`load_state`): the run continues after the iteration it holds --
+    ``x0`` is ignored and no misfit is re-evaluated -- and, ``fg`` being deterministic, reproduces the
+    uninterrupted run bit for bit (``maxiter`` counts iterations of the whole run, not of this call).
     """
     dot = dot or (lambda a, b: float(np.sum(np.multiply(a, b, dtype=np.float64))))  # no BLAS threads
     if int(history) < 1:
@@ -30,12 +61,19 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
     def project(x):
         return np.clip(x, lo, hi) if bounds is not None else x
 
-    x = project(np.array(x0, copy=True))
-    f, g = fg(x)
-    _require_finite(f, float(np.abs(g).max()), dot(g, g), 0)
-    S, Y, log = [], [], [{"iter": 0, "f": f, "evals": 1}]
-    evals = 1
-    for it in range(1, maxiter + 1):
+    if resume is not None:
+        st = load_state(resume) if isinstance(resume, (str, os.PathLike)) else resume
+        x, f, g, S, Y = st["x"], st["f"], st["g"], list(st["S"]), list(st["Y"])
+        log, evals, it0 = list(st["log"]), st["evals"], st["it"]
+    else:
+        x = project(np.array(x0, copy=True))
+        f, g = fg(x)
+        _require_finite(f, float(np.abs(g).max()), dot(g, g), 0)
+        S, Y, log = [], [], [{"iter": 0, "f": f, "evals": 1}]
+        evals, it0 = 1, 0
+        if checkpoint:
+            save_state(checkpoint, 0, x, f, g, S, Y, log, evals)
+    for it in range(it0 + 1, maxiter + 1):
         if not float(np.abs(g).max()) > gtol:
             break  # stationary (or projected onto a bound everywhere)
         q = np.array(g, copy=True)
@@ -88,6 +126,8 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         x, f, g = xn, fn, gn
         _require_finite(f, float(np.abs(g).max()), dot(g, g), it)
         log.append({"iter": it, "f": f, "evals": evals, "step": t})
+        if checkpoint:
+            save_state(checkpoint, it, x, f, g, S, Y, log, evals)
         if callback:
             callback(it, x, f, g)
     return x, f, log
@@ -111,13 +151,17 @@ def _require_finite(f, gmax, gg, it):
 
 
 def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=None, c1=1e-4, max_ls=8,
-                 gtol=0.0, callback=None, c2=0.9):
+                 gtol=0.0, callback=None, c2=0.9, checkpoint=None, resume=None):
     """The same iteration as :func:`lbfgs` with every model-sized vector resident on the GPU
     (``Engine.vec_*`` slots): per iteration only scalars cross PCIe.
 
     ``fg(x_slot, g_slot) -> f`` evaluates the misfit at the model in ``x_slot`` and leaves the
     gradient in ``g_slot`` (see ``shots.misfit_and_gradient_device``).  Returns ``(x, f, log)``
     with ``x`` downloaded once at the end.
+
+    ``checkpoint`` / ``resume``: as in :func:`lbfgs` (the state file is the same: a run may be saved by one and
+    resumed by the other); saving downloads the model, the gradient and the curvature pairs once per iteration
+    (2 + 2 x history model-sized arrays over PCIe: ~0.1 s at 256^3 against ~7 s of shots per evaluation).
     """
     m = int(history)
     if m < 1:
@@ -127,16 +171,34 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
     # once the candidate has passed the curvature test
     S0, Y0 = 7, 7 + (m + 1)
     engine.vec_create(7 + 2 * (m + 1))
-    engine.vec_upload(X, x0)
-    if bounds is not None:
-        engine.vec_clip(X, *bounds)
-    f = fg(X, G)
-    _require_finite(f, engine.vec_absmax(G), engine.vec_dot(G, G), 0)
     pairs = []  # ring of (s_slot, y_slot), oldest first
     free = list(range(m + 1))
-    log = [{"iter": 0, "f": f, "evals": 1}]
-    evals = 1
-    for it in range(1, maxiter + 1):
+
+    def save(it, f, log, evals):
+        save_state(checkpoint, it, engine.vec_download(X), f, engine.vec_download(G),
+                   [engine.vec_download(s) for s, _ in pairs], [engine.vec_download(y) for _, y in pairs], log, evals)
+
+    if resume is not None:
+        st = load_state(resume) if isinstance(resume, (str, os.PathLike)) else resume
+        engine.vec_upload(X, st["x"])
+        engine.vec_upload(G, st["g"])
+        for s_h, y_h in list(zip(st["S"], st["Y"]))[-m:]:
+            k = free.pop(0)
+            engine.vec_upload(S0 + k, s_h)
+            engine.vec_upload(Y0 + k, y_h)
+            pairs.append((S0 + k, Y0 + k))
+        f, log, evals, it0 = st["f"], list(st["log"]), st["evals"], st["it"]
+    else:
+        engine.vec_upload(X, x0)
+        if bounds is not None:
+            engine.vec_clip(X, *bounds)
+        f = fg(X, G)
+        _require_finite(f, engine.vec_absmax(G), engine.vec_dot(G, G), 0)
+        log = [{"iter": 0, "f": f, "evals": 1}]
+        evals, it0 = 1, 0
+        if checkpoint:
+            save(0, f, log, evals)
+    for it in range(it0 + 1, maxiter + 1):
         gmax = engine.vec_absmax(G)
         if not gmax > gtol:
             break
@@ -207,6 +269,8 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
         f = fn
         _require_finite(f, engine.vec_absmax(G), engine.vec_dot(G, G), it)
         log.append({"iter": it, "f": f, "evals": evals, "step": t})
+        if checkpoint:
+            save(it, f, log, evals)
         if callback:
             callback(it, X, f, G)
     return engine.vec_download(X), f, log

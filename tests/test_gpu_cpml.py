@@ -104,7 +104,7 @@ def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
     assert e_sponge > 0.05 and e_cpml < 2e-3
 
 
-@pytest.mark.parametrize("shape,npml,nt", [((192, 256), 40, 72), ((150, 216), 6, 41)])
+@pytest.mark.parametrize("shape,npml,nt", [((192, 256), 40, 120), ((150, 216), 6, 101)])
 def test_cpml_inside_the_fused_launch_equals_the_slab_path(gpu, monkeypatch, shape, npml, nt):
     """The same shot through step2d_fused with the border recursion inside the launch and through step2d_tile +
     slab kernels (FWI_NO_FUSED2D_CPML=1): seismograms, F^T r and gradient agree to fp32 round-off."""
@@ -113,8 +113,9 @@ def test_cpml_inside_the_fused_launch_equals_the_slab_path(gpu, monkeypatch, sha
     h, order = 10.0, 8
     dt = 0.7 * fo.cfl_dt(float(c.max()), h, 2, order)
     src = np.array([[3, shape[1] // 2], [shape[0] // 2, 2]])
-    rec = np.array([[1, 1], [shape[0] - 1, shape[1] - 1], [shape[0] // 2, shape[1] // 3], [2, shape[1] - 3]])
-    wav = np.stack([fo.ricker(nt, dt, 0.1 / dt / 8), fo.ricker(nt, dt, 0.1 / dt / 5)], 1).astype(np.float32)
+    rec = np.array([[1, shape[1] // 2 - 3], [8, shape[1] // 2 + 6], [shape[0] // 2 + 5, 1], [shape[0] // 2 - 7, 9]])
+    f0 = 1.0 / (24.0 * dt)  # 24 steps per period, onset well inside the run
+    wav = np.stack([fo.ricker(nt, dt, f0, t0=1.2 / f0), fo.ricker(nt, dt, 0.7 * f0, t0=1.0 / f0)], 1).astype(np.float32)
     out = []
     for env in (None, "1"):
         if env:
@@ -125,8 +126,8 @@ def test_cpml_inside_the_fused_launch_equals_the_slab_path(gpu, monkeypatch, sha
             a = e.adjoint(d)
             out.append((kern, d, a, e.gradient()))
     assert out[0][0] == "step2d_fused" and out[1][0] == "step2d_tile"
-    for i in (1, 2, 3):
-        assert rel(out[0][i], out[1][i]) < 2e-6, (i, rel(out[0][i], out[1][i]))
+    for i in (1, 2, 3):  # (two summation orders of the same recursion, 100+ steps deep in the border)
+        assert rel(out[0][i], out[1][i]) < 1e-5, (i, rel(out[0][i], out[1][i]))
 
 
 def test_cpml_configuration_errors(gpu):

@@ -57,3 +57,31 @@ def test_bf16_store_keeps_a_nan_a_nan(gpu):
             out.append(eng.gradient())
     assert np.isfinite(out[0]).all()
     assert np.linalg.norm(out[0] - out[1]) < 2e-2 * np.linalg.norm(out[1])
+
+
+def test_device_lbfgs_resumes_from_its_state_file(gpu, tmp_path):
+    """The device-resident optimiser writes its state after every iteration (model, gradient and curvature pairs
+    downloaded once); a run resumed from the file of iteration 2 ends where the uninterrupted run ended.  (fp32
+    gradients carry float atomics in the injection, so "equal" is to round-off here; the host optimiser's resume
+    is bit-exact, tests/test_host_logic.py.)"""
+    import shutil
+    from full_waveform_inversion_amd import shots as sh, workloads
+    from full_waveform_inversion_amd.lbfgs import lbfgs, lbfgs_device, load_state
+    w = workloads.cfg5(0.1875, nshots=3)  # 48^3 (two of its shots)
+    wav = w.wavelet()
+    shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(2)]
+    x0 = w.c_init.astype(np.float32)
+    ck, ck2 = str(tmp_path / "s.npz"), str(tmp_path / "s2.npz")
+    kw = dict(maxiter=4, history=3, first_step=40.0, bounds=(1000.0, 5000.0))
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) as e:
+        sh.model_data(e, w.c.astype(np.float32), shots)
+        fg = lambda xs, gs: sh.misfit_and_gradient_device(e, xs, gs, shots)  # noqa: E731
+        x_ref, f_ref, log_ref = lbfgs_device(e, fg, x0, checkpoint=ck,
+                                             callback=lambda it, *_: it == 2 and shutil.copy(ck, ck2), **kw)
+        assert load_state(ck2)["it"] == 2 and load_state(ck)["it"] == 4
+        x2, f2, log2 = lbfgs_device(e, fg, None, resume=ck2, **kw)
+        # and the host optimiser can pick the same file up
+        x3, f3, log3 = lbfgs(lambda m: sh.misfit_and_gradient(e, m, shots), None, resume=ck2, dot=e.dot, **kw)
+    assert [r["evals"] for r in log2] == [r["evals"] for r in log_ref] == [r["evals"] for r in log3]
+    assert abs(f2 - f_ref) <= 1e-5 * f_ref and abs(f3 - f_ref) <= 1e-4 * f_ref
+    assert np.linalg.norm(x2 - x_ref) <= 1e-6 * np.linalg.norm(x_ref)

@@ -262,6 +262,44 @@ def test_lbfgs_quadratic_and_rosenbrock():
     assert f < 1e-8 and np.allclose(x, 1.0, atol=1e-3)
 
 
+def test_lbfgs_state_save_and_resume_reproduce_the_uninterrupted_run(tmp_path):
+    """SURVEY s.5 "checkpoint / resume": the optimiser state is written after every iteration; a run resumed from the
+    file of iteration 3 reproduces the uninterrupted 7-iteration run BIT FOR BIT (model, misfit, log) and evaluates
+    nothing twice; the file survives being resumed from repeatedly, and a dict works like a path."""
+    import shutil
+    from full_waveform_inversion_amd.lbfgs import load_state
+
+    def rosen(x):  # extended Rosenbrock, 12 unknowns
+        f = float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2))
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2.0 * (1.0 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    x0 = np.linspace(-1.2, 1.0, 12)
+    calls = {"n": 0}
+
+    def counted(x):
+        calls["n"] += 1
+        return rosen(x)
+
+    ck, ck3 = str(tmp_path / "state.npz"), str(tmp_path / "state_it3.npz")
+    x_ref, f_ref, log_ref = lbfgs(counted, x0, maxiter=7, history=3, first_step=0.1, max_ls=20, bounds=(-2.0, 2.0),
+                                  checkpoint=ck, callback=lambda it, *_: it == 3 and shutil.copy(ck, ck3))
+    total = calls["n"]
+    assert load_state(ck)["it"] == 7 and load_state(ck3)["it"] == 3 and len(load_state(ck3)["S"]) == 3
+    calls["n"] = 0
+    x2, f2, log2 = lbfgs(counted, None, maxiter=7, history=3, first_step=0.1, max_ls=20, bounds=(-2.0, 2.0), resume=ck3)
+    assert np.array_equal(x2, x_ref) and f2 == f_ref and log2 == log_ref
+    assert calls["n"] == total - log_ref[3]["evals"]          # only the evaluations after iteration 3
+    x3, f3, log3 = lbfgs(counted, None, maxiter=7, history=3, first_step=0.1, max_ls=20, bounds=(-2.0, 2.0),
+                         resume=load_state(ck3))
+    assert np.array_equal(x3, x_ref) and log3 == log_ref
+    # resuming a finished run does nothing
+    x4, f4, log4 = lbfgs(counted, None, maxiter=7, history=3, resume=ck)
+    assert np.array_equal(x4, x_ref) and log4 == log_ref
+
+
 def test_lbfgs_recovers_from_a_far_too_long_first_step_in_few_evaluations():
     """A first step 100x too long: interpolating the parabola through f(0), f'(0) and the failed trial finds the
     scale in two or three misfit evaluations (each one a sweep over all shots) where halving needs seven."""
