@@ -66,6 +66,7 @@ struct fwi_ctx {
     int fused_skipd = -1;  // Fused2dArgs::skipd (FWI_FUSED2D_SKIPD, read at create)
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
+    bool xpml = false;  // 3-D fp32 stream contexts: the x border's recursion runs inside the step kernel
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
@@ -289,6 +290,10 @@ struct Impl {
         a.npml = ctx->cfg.npml;
         a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
                                   ((double)ctx->cfg.npml * ctx->cfg.npml)) : T(0);
+        a.xp_mode = 0;
+        a.xp_psi = a.xp_zeta = nullptr;
+        a.xp_a = a.xp_b = nullptr;
+        for (int k = 0; k < 5; ++k) a.xp_dk[k] = a.xp_dk1[k] = T(0);
         a.inj_start = nullptr;
         a.inj_pidx = a.inj_cidx = nullptr;
         a.inj_cu = a.inj_cq = a.inj_amp = nullptr;
@@ -901,10 +906,23 @@ struct Impl {
             }
             if (ctx->cpml) {  // memory variables of the border advance with the newest field ...
                 const PmlArgs<T> p = pml_args(ctx, sw, a.q_out);
-                HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream));
-                HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream));
+                int axes = 7;
+                if (ctx->xpml) {  // ... the x border's inside the step kernel itself (step3d_stream, XP)
+                    axes = 3;
+                    a.xp_mode = dn < 0 ? 2 : 1;
+                    a.xp_psi = p.psi[2];
+                    a.xp_zeta = p.zeta[2];
+                    a.xp_a = p.a[2];
+                    a.xp_b = p.b[2];
+                    for (int k = 0; k < 5; ++k) {
+                        a.xp_dk[k] = p.dk[k];
+                        a.xp_dk1[k] = p.dk1[k];
+                    }
+                }
+                HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream, axes));
+                HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream, axes));
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
-                HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream));  // ... and their term joins u' (and q)
+                HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream, axes));  // ... and their term joins u' (and q)
             } else {
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
             }
@@ -1551,6 +1569,8 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
             }
         }
     }
+    ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !ctx->inc && !getenv("FWI_NO_STREAM_XPML") &&
+                stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||

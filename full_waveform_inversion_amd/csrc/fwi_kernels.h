@@ -53,6 +53,14 @@ struct StepArgs {
     int npml;        // border width; with dz_scale lets the stream kernel form dz[z] without a load
     T dz_scale;      // sigma_max dt / (2 npml^2): d_z(z) = dz_scale * dist(z)^2
 
+    // Convolutional PML of the x border INSIDE the 3-D stream kernel (fp32, standard form; xp_mode 0 = off, 1 = the
+    // forward recursion, 2 = its transpose): memory variables in the slab kernels' layout (nz, ny, 2 npml), 1-D
+    // coefficients over x, first-difference weights dk (of a memory variable) / dk1 (of the field), see PmlArgs.
+    int xp_mode;
+    T *xp_psi, *xp_zeta;
+    const T *xp_a, *xp_b;
+    T xp_dk[5], xp_dk1[5];
+
     // Point operations fused into the step kernels (all nullptr / 0 = none).
     // Injection into u_next (and q_out): entries sorted by workgroup tile,
     // inj_start[tile] .. inj_start[tile + 1] is the tile's slice.
@@ -149,8 +157,11 @@ struct PmlArgs {
     int npml;
 };
 // phase 1, 2: advance the memory variables (before the step kernel); 3: add their term to u' (after it)
+// `axes`: bit d set = run axis d (z = 1, y = 2, x = 4); an axis the step kernel carries itself is left out
 template <typename T>
-hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s);
+hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes = 7);
+// True when the 3-D stream kernel can carry the x border's recursion in its lanes (see step3d_stream, XP)
+bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32);
 
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch

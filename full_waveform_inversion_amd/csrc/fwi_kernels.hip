@@ -270,8 +270,13 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 
 // IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
+// XP: the convolutional PML of the x border carried in the lanes (1 = forward recursion, 2 = its transpose): the
+// border cells of a row are the first / last npml / 4 lanes of the wave that owns it, psi' of the neighbouring cells
+// comes through __shfl_up / __shfl_down (the 2 r-wide dependence of the border recursion never leaves the wave),
+// D u and E_x u from the x window the stencil has in registers anyway.  The memory variables are read and written
+// once per step by the lanes that own them -- no slab launches for this axis, no second pass over u' and q.
 template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false,
-          bool QB = false>
+          bool QB = false, int XP = 0>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk, int tw) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -365,6 +370,29 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         }
     }
 
+    // x-border CPML in the lanes: a(x), b(x) of this lane's cells (0 off the border, so that psi and zeta vanish
+    // there whatever was loaded), the lane's offset in a row of the memory-variable arrays (nz, ny, 2 npml)
+    V xca, xcb;
+    unsigned xld = 0;
+    bool xin = false;
+    int64_t xplane = 0;
+    if constexpr (XP != 0) {
+        const int nsl = 2 * a.npml;
+        xplane = (int64_t)g.ny * nsl;
+        bool in = false;
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+            const int x = x0 + j;
+            const bool b = x < g.nx && (x < a.npml || x >= g.nx - a.npml);
+            xca.v[j] = b ? a.xp_a[x] : T(0);
+            xcb.v[j] = b ? a.xp_b[x] : T(0);
+            in |= b;
+        }
+        xin = act && in;  // (npml and nx are multiples of VL here: a lane's cells are all in the border or all out)
+        const int jx = x0 < a.npml ? x0 : x0 - (g.nx - nsl);
+        xld = (unsigned)((int64_t)min(y, g.ny - 1) * nsl + (xin ? jx : 0));  // lanes off the border re-read column 0
+    }
+
     // z register queue: plane p lives in slot (p - z0 + R) % NQ.  PF planes are fetched ahead of
     // use straight into the queue; the pointwise operands (u_prev, C), halo rows and edge pieces
     // sit in rings of PF + 1 slots.  NQ is a multiple of PF + 1 and the z loop is unrolled NQ
@@ -384,6 +412,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
 #pragma unroll
     for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
     V up[NR], Cc[NR], halo[NRH][NH];
+    V xps[XP ? NR : 1], xzt[XP ? NR : 1];  // psi / zeta (adjoint: pt / zt) of the x border, fetched like up / Cc
     T edge[NR];
     // increment form: the pointwise operand is v^n (its own padded field) instead of u^{n-1}
     const T *const pw = INC ? a.v : a.u_prev;
@@ -393,6 +422,10 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         up[p] = ldv<T>(pw + o + poff);
         Cc[p] = ldv<T>(a.C + o + poff);
         edge[p] = a.u_cur[o + eoff];
+        if constexpr (XP != 0) {
+            xps[p] = ldv<T>(a.xp_psi + (int64_t)min(z0 + p, g.nz - 1) * xplane + xld);
+            xzt[p] = ldv<T>(a.xp_zeta + (int64_t)min(z0 + p, g.nz - 1) * xplane + xld);
+        }
     }
 #pragma unroll
     for (int p = 0; p < HPF; ++p) {
@@ -430,6 +463,11 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
             up[nxt] = ldv<T>(pw + on + poff);
             Cc[nxt] = ldv<T>(a.C + on + poff);
+            if constexpr (XP != 0) {
+                const int64_t ox = (int64_t)min(z + PF, g.nz - 1) * xplane + xld;
+                xps[nxt] = ldv<T>(a.xp_psi + ox);
+                xzt[nxt] = ldv<T>(a.xp_zeta + ox);
+            }
             V qi, qi2, gi;
             if (IMAGE) {
                 const unsigned co = act ? coff : 0u;
@@ -469,6 +507,72 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     lap.v[j] = fma(c, t, lap.v[j]);
                 }
             }
+            // x-border CPML: this lane's cells of the border recursion, neighbours through the wave
+            V xterm, xn0, xn1;
+            if constexpr (XP != 0) {
+                T W[2 * HALO + VL];  // [left lane's cells][own][right lane's] of a quantity, zero beyond the wave
+                auto spread = [&](const V &v) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        const T l = __shfl_up(v.v[j], 1, 64), r = __shfl_down(v.v[j], 1, 64);
+                        W[j] = lane == 0 ? T(0) : l;
+                        W[HALO + j] = v.v[j];
+                        W[HALO + VL + j] = lane == 63 ? T(0) : r;
+                    }
+                };
+                const V m0 = xps[cur], m1 = xzt[cur];
+                if (XP == 1) {
+                    // psi' = b psi + a D u;  zeta' = b zeta + a (E_x u + D psi');  term = D psi' + zeta'
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T du = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) du = fma(a.xp_dk1[k], X[HALO + j + k] - X[HALO + j - k], du);
+                        xn0.v[j] = fma(xcb.v[j], m0.v[j], xca.v[j] * du);
+                    }
+                    spread(xn0);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T dp = T(0), ex = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            dp = fma(a.xp_dk[k], W[HALO + j + k] - W[HALO + j - k], dp);
+                            ex = fma(a.ck[k], fma(T(-2), X[HALO + j], X[HALO + j - k] + X[HALO + j + k]), ex);
+                        }
+                        xn1.v[j] = fma(xcb.v[j], m1.v[j], xca.v[j] * (ex + dp));
+                        xterm.v[j] = dp + xn1.v[j];
+                    }
+                } else {
+                    // zt' = b zt + mu;  pt' = b pt - D mu - D (a zt');  term = E_x (a zt') - D (a pt')
+                    V al;
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        xn1.v[j] = fma(xcb.v[j], m1.v[j], X[HALO + j]);
+                        al.v[j] = xca.v[j] * xn1.v[j];
+                    }
+                    spread(al);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T d = T(0), e2 = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            d = fma(a.xp_dk1[k], (X[HALO + j + k] - X[HALO + j - k]) + (W[HALO + j + k] - W[HALO + j - k]), d);
+                            e2 = fma(a.ck[k], fma(T(-2), W[HALO + j], W[HALO + j + k] + W[HALO + j - k]), e2);
+                        }
+                        xn0.v[j] = xcb.v[j] * m0.v[j] - d;
+                        xterm.v[j] = e2;
+                        al.v[j] = xca.v[j] * xn0.v[j];  // (now beta = a pt')
+                    }
+                    spread(al);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T db = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) db = fma(a.xp_dk[k], W[HALO + j + k] - W[HALO + j - k], db);
+                        xterm.v[j] -= db;
+                    }
+                }
+            }
 
             V A = Axy, B = Bxy;
             if (DAMP) {
@@ -489,7 +593,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             V q, un, vn;
 #pragma unroll
             for (int j = 0; j < VL; ++j) {
-                q.v[j] = Cc[cur].v[j] * lap.v[j];
+                q.v[j] = XP ? Cc[cur].v[j] * (lap.v[j] + xterm.v[j]) : Cc[cur].v[j] * lap.v[j];
                 if (INC) {  // v' = A (B v + q), u' = u + v'
                     vn.v[j] = DAMP ? fma(B.v[j], up[cur].v[j], q.v[j]) * A.v[j] : up[cur].v[j] + q.v[j];
                     un.v[j] = X[HALO + j] + vn.v[j];
@@ -497,6 +601,12 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     un.v[j] = (fma(T(2), X[HALO + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
                 else
                     un.v[j] = (T(2) * X[HALO + j] - up[cur].v[j]) + q.v[j];
+            }
+            if constexpr (XP != 0) {
+                if (xin) {
+                    stv<T>(a.xp_psi + (int64_t)z * xplane + xld, xn0);
+                    stv<T>(a.xp_zeta + (int64_t)z * xplane + xld, xn1);
+                }
             }
             if (act) {
                 if (INC) stv<T>(a.v + (int64_t)z * sz + poff, vn);
@@ -674,6 +784,15 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
     return g.ndim == 3;                       // double2 lanes: 3-D stream kernel only
 }
 
+bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32) {
+    if (g.ndim != 3 || !is_f32 || g.r != 4 || npml < 4) return false;
+    if (npml % 4 || g.nx % 4) return false;            // a lane's four cells lie wholly inside or outside the border
+    if (g.nx < 2 * (npml + g.r)) return false;         // the two borders (and their reach) do not meet
+    const int tw = t.tile_x, nxt = stream_nxt(g, tw);
+    // each border and the r cells it reaches into lie inside ONE tile row, i.e. inside one wave
+    return tw >= npml + g.r && g.nx - (nxt - 1) * tw >= npml + g.r;
+}
+
 StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
     const int full_x = is_f32 ? 256 : 128, vl = is_f32 ? 4 : 2;
     // 3-D: split nx into equal x tiles (multiples of the lane vector) rather than full ones plus a remainder
@@ -774,6 +893,29 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
                                    a, g, zchunk, nxt, nyt, nblk, tw);
             else
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, true>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (std::is_same<T, float>::value && R == 4 && !DAMP) {
+        if (a.xp_mode == 1) {  // x-border CPML in the lanes, forward recursion
+            if (a.q_out)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 1>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+        if (a.xp_mode == 2) {  // ... its transpose (the adjoint sweep)
+            if (a.q_in && a.q_in2)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 2>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else if (a.q_in)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 2>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 2>), grid, block, 0, s,
                                    a, g, zchunk, nxt, nyt, nblk, tw);
             return hipGetLastError();
         }

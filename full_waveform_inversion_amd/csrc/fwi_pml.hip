@@ -426,32 +426,32 @@ static void launch_pml_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse,
 }
 
 template <typename T, int R, int PHASE>
-static hipError_t launch_pml_phase(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
-    launch_pml_axis<T, R, 0, PHASE>(g, p, reverse, s);
-    if (g.ndim == 3) launch_pml_axis<T, R, 1, PHASE>(g, p, reverse, s);
-    launch_pml_axis<T, R, 2, PHASE>(g, p, reverse, s);
+static hipError_t launch_pml_phase(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes) {
+    if (axes & 1) launch_pml_axis<T, R, 0, PHASE>(g, p, reverse, s);
+    if (g.ndim == 3 && (axes & 2)) launch_pml_axis<T, R, 1, PHASE>(g, p, reverse, s);
+    if (axes & 4) launch_pml_axis<T, R, 2, PHASE>(g, p, reverse, s);
     return hipGetLastError();
 }
 
 template <typename T, int R>
-static hipError_t launch_pml_r(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
+static hipError_t launch_pml_r(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes) {
     switch (phase) {
-        case 1: return launch_pml_phase<T, R, 1>(g, p, reverse, s);
-        case 2: return reverse ? launch_pml_phase<T, R, 2>(g, p, reverse, s) : hipSuccess;  // forward: inside phase 3
-        default: return launch_pml_phase<T, R, 3>(g, p, reverse, s);
+        case 1: return launch_pml_phase<T, R, 1>(g, p, reverse, s, axes);
+        case 2: return reverse ? launch_pml_phase<T, R, 2>(g, p, reverse, s, axes) : hipSuccess;  // forward: inside phase 3
+        default: return launch_pml_phase<T, R, 3>(g, p, reverse, s, axes);
     }
 }
 
 template <typename T>
-hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s) {
+hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes) {
     switch (g.r) {
-        case 1: return launch_pml_r<T, 1>(g, p, phase, reverse, s);
-        case 2: return launch_pml_r<T, 2>(g, p, phase, reverse, s);
-        default: return launch_pml_r<T, 4>(g, p, phase, reverse, s);
+        case 1: return launch_pml_r<T, 1>(g, p, phase, reverse, s, axes);
+        case 2: return launch_pml_r<T, 2>(g, p, phase, reverse, s, axes);
+        default: return launch_pml_r<T, 4>(g, p, phase, reverse, s, axes);
     }
 }
 
-template hipError_t launch_pml<float>(const GridDesc &, const PmlArgs<float> &, int, int, hipStream_t);
-template hipError_t launch_pml<double>(const GridDesc &, const PmlArgs<double> &, int, int, hipStream_t);
+template hipError_t launch_pml<float>(const GridDesc &, const PmlArgs<float> &, int, int, hipStream_t, int);
+template hipError_t launch_pml<double>(const GridDesc &, const PmlArgs<double> &, int, int, hipStream_t, int);
 
 }  // namespace fwi

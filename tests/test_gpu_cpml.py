@@ -31,6 +31,11 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((70, 90), 8, 8, 40.0, "float32", TOL32, "step2d_tile", {}),          # 2-D: one step per launch with the CPML
     ((70, 91), 2, 7, 0.0, "float32", TOL32, "step2d_tile", {}),
     ((70, 90), 8, 8, 40.0, "float64", TOL64, "step_point", {}),
+    # 3-D grids whose x border runs inside step3d_stream's lanes (stream_xpml_supported: npml, nx multiples of 4)
+    ((40, 36, 64), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"ckpt_interval": 16}),
+    ((20, 18, 300), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {}),           # two x tiles of 152 / 148 columns
+    ((24, 16, 256), 8, 16, 20.0, "float32", TOL32, "step3d_stream", {}),          # full 256-column tiles (FULL path)
+    ((30, 24, 40), 8, 12, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 7}), # several z chunks per tile
     # grids the fused 2-D kernel takes WITH the border recursion inside the launch (fused2d_cpml_supported): 70 steps
     # = 68 in 4-step launches + 2 through the slab path, on the same memory variables
     ((192, 256), 8, 40, 40.0, "float32", TOL32, "step2d_fused", {}),            # cfg2's border width, 48-cell images
