@@ -13,15 +13,23 @@ No torch in this process: the launcher only provides RANK / WORLD_SIZE / MASTER_
 the C-ABI, and the max-over-ranks of the elapsed time goes through RCCL too (fwi_allreduce_f64_max).
 With N > 1 any RCCL failure is fatal (non-zero exit): there is no host-side fallback for the sum.
 
-At N = 1 the same invocation also runs three short extra legs and reports them in the same JSON line
-(`legs`, and `roofline.hbm_regime`): the 512^3 forward run (working set past the 256 MiB Infinity Cache:
-the honest HBM number), the 256^3 gradient shot (forward + store, adjoint + imaging) and configs[1]
-(2-D 1024^2 x 2000 steps).  `--leg NAME` runs one leg alone (what the rocprofv3 passes use).
+At N = 1 the same invocation also runs short extra legs and reports them in the same JSON line (`legs`, and
+`roofline.hbm_regime`): the 512^3 forward run (working set past the 256 MiB Infinity Cache: the honest HBM
+number), the 256^3 gradient shot (forward + store, adjoint + imaging) in the standard and in the increment update
+form (the fp32 mode that meets north_star's 1e-5 end to end), configs[1] (2-D 1024^2 x 2000 steps) with the sponge
+and with the convolutional PML, and the 256^3 / npml 16 run with the convolutional PML.  `--leg NAME` runs one leg
+alone (what the rocprofv3 passes use).
+
+For every N (also N = 1 under FWI_BENCH_FORCE_EXCHANGE=1) `legs.gradient` is the path's real multi-GPU pattern
+(configs[2] / configs[4]): per shot forward + store and adjoint + imaging into the device accumulator, then the ONE
+RCCL all-reduce of that accumulator, with a check in the line: g.g after the sum = N^2 x g.g before it (every rank
+runs the same shot, so the sum is N g).
 """
 import argparse
 import faulthandler
 import json
 import os
+import socket
 import sys
 import time
 
@@ -70,25 +78,27 @@ def cpu_baseline(w, sample_steps):
 
 def measured_traffic(leg):
     """Fabric-side bytes per launch of `leg`'s dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_traffic.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
+    (profiles/r03_traffic.json, else r02_traffic.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
     WRITE_SIZE runs of `bench.py --leg <leg>`), or None.  PMC counters cannot be collected in-process."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    try:
-        ent = json.load(open(path)).get(leg)
-    except (OSError, ValueError):
-        return None, None
-    if not ent:
-        return None, None
-    return ent.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT) + "#" + leg
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            ent = json.load(open(path)).get(leg)
+        except (OSError, ValueError):
+            continue
+        if ent:
+            return ent.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT) + "#" + leg
+    return None, None
 
 
 def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, exchange=None, barrier=None,
-            max_over_ranks=None):
+            max_over_ranks=None, dtype=None):
     """Time `steps` shots of a workload; returns (workload, per-shot wall s, kernel us/launch, info)."""
     from full_waveform_inversion_amd import Engine
     w = make_workload()
-    wav = w.wavelet()
-    model = w.c.astype(np.float32)
+    ft = np.float64 if dtype == "float64" else np.float32
+    wav = w.wavelet(ft)
+    model = w.c.astype(ft)
     kw = dict(order=w.order, npml=w.npml, device=device)
     kw.update(engine_kw or {})
     e = Engine(w.shape, w.h, w.dt, w.nt, **kw)
@@ -108,39 +118,61 @@ def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, ex
 
         for _ in range(warmup):
             step()
-        if ex is not None:
+        if ex is not None and grad:
             e.allreduce_gradient()  # warm the communicator (the first collective sets up the rings)
+        check = None
+        if grad and ex is not None:
+            e.vec_create(1)  # scratch for the check below (outside the timed region)
+        e.reset_gradient()
         if barrier:
             barrier()
         e.synchronize()
         t0 = time.perf_counter()
         loop_ms = [step() for _ in range(steps)]
-        if ex is not None:
+        e.synchronize()
+        t_shots = time.perf_counter() - t0
+        if grad and ex is not None:  # untimed: g.g of this rank's accumulated gradient before the sum
+            e.gradient_vec(0, "slowness2")
+            gg_before = e.vec_dot(0, 0)
+            e.synchronize()
+        t1 = time.perf_counter()
+        if ex is not None and grad:
             e.allreduce_gradient()  # the shot loop's one exchange: sum of the per-rank gradients
         e.synchronize()
         if barrier:
             barrier()
-        el = time.perf_counter() - t0
+        el = t_shots + (time.perf_counter() - t1)
+        allreduce_ms = 1e3 * (time.perf_counter() - t1) if (ex is not None and grad) else None
+        if grad and ex is not None:
+            e.gradient_vec(0, "slowness2")
+            gg_after = e.vec_dot(0, 0)
+            nr = ex.rccl_ranks
+            ratio = gg_after / gg_before if gg_before > 0 else float("nan")
+            check = {"g_dot_g_before_sum": gg_before, "g_dot_g_after_sum": gg_after, "ratio": ratio,
+                     "expected_ratio": float(nr * nr), "ok": bool(abs(ratio - nr * nr) <= 1e-4 * nr * nr),
+                     "note": "every rank runs the same shots, so the all-reduced accumulator is N x the local one"}
         if max_over_ranks:
             el = max_over_ranks(e, el)
         sweeps = 2 if grad else 1
         info = {"kernel": e.kernel_name, "set_model_ms": round(set_model_ms, 1),
-                "rccl_ranks": ex.rccl_ranks if ex is not None else None}
+                "rccl_ranks": ex.rccl_ranks if ex is not None else None, "allreduce_check": check,
+                "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 3)}
         return w, el, 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps), info
     finally:
         e.close()
 
 
-def roofline_entry(leg, w, kern_us, bpu, bound, note, steps_per_launch=1):
-    """`kern_us`: HIP-event time of the step loop / launches; one launch advances `steps_per_launch` time steps."""
+def roofline_entry(leg, w, kern_us, bpu, bound, note, steps_per_launch=1, extra_bytes=0):
+    """`kern_us`: HIP-event time of the step loop / launches; one launch advances `steps_per_launch` time steps.
+    `extra_bytes`: algorithmic bytes per launch beside the per-update figure (the CPML's memory variables)."""
     npts = int(np.prod(w.shape)) * steps_per_launch
-    achieved = bpu * npts / (kern_us * 1e-6) / 1e9
+    achieved = (bpu * npts + extra_bytes) / (kern_us * 1e-6) / 1e9
     traffic, src = measured_traffic(leg)
     return {"bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_achievable_hbm": round(achieved / HBM_COPY_GBS, 4),
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": src,
-            "algorithmic_bytes_per_launch": bpu * npts, "kernel_avg_us": round(kern_us, 3), "note": note}
+            "algorithmic_bytes_per_launch": bpu * npts + extra_bytes, "kernel_avg_us": round(kern_us, 3), "note": note}
 
 
 def main():
@@ -157,7 +189,8 @@ def main():
                     help="gradient mode: store / correlate the forward term every S-th step (fwi_config.image_stride)")
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
                     help="headline leg: forward = the stencil run; gradient = forward(save) + adjoint(imaging) per step")
-    ap.add_argument("--leg", default="all", choices=["all", "headline", "hbm", "gradient", "cfg2"],
+    ap.add_argument("--leg", default="all", choices=["all", "headline", "hbm", "gradient", "gradient_increment", "cfg2",
+                                                     "cfg2_cpml", "cpml3d", "fp64", "point", "bf16"],
                     help="all: headline + (at N = 1) the three extra legs; or one leg alone (profiling passes)")
     ap.add_argument("--leg-nt", type=int, default=0, help="time steps of a --leg run (0 = the leg's own)")
     ap.add_argument("--cpu-steps", type=int, default=200,
@@ -188,7 +221,7 @@ def main():
         sys.exit("bench.py: %d ranks but only %d visible GPUs (RCCL refuses two ranks on one device)" % (world, ndev))
 
     from full_waveform_inversion_amd import workloads
-    from full_waveform_inversion_amd.rendezvous import Rendezvous
+    from full_waveform_inversion_amd.rendezvous import Rendezvous, RendezvousError
     from full_waveform_inversion_amd.shots import RcclExchange
 
     # FWI_BENCH_FORCE_EXCHANGE=1: take the N > 1 code path (rendezvous, RCCL communicator, timed all-reduce, max over
@@ -243,8 +276,11 @@ def main():
                                        "O(8), npml=%d" % ("x".join(map(str, w.shape)), w.nt, w.npml),
                            "kernel": info["kernel"], "image_stride": S,
                            "parallelism": "shot-parallel x%d" % world,
-                           "exchange": "none" if not multi else
-                                       "one rccl allreduce of the gradient accumulator after the K shots (timed)",
+                           "exchange": "none" if not multi else (
+                                       "one rccl allreduce of the gradient accumulator after the K shots (timed)" if grad
+                                       else "none in this forward-only leg (shots are independent; the slowest rank's "
+                                            "time is taken with a 1-double rccl allreduce); the gradient all-reduce of "
+                                            "configs[2] / configs[4] is timed in legs.gradient"),
                            "rccl_ranks": info["rccl_ranks"], "control_plane": "stdlib tcp rendezvous (no torch)"},
                 "roofline": roofline_entry(
                     "headline" if (args.grid == 256 and not grad) else "other", w, kern_us, bpu,
@@ -272,21 +308,45 @@ def main():
         r["Gpts_per_s"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
         r["kernel"] = info["kernel"]
         legs["hbm"] = r
-    if want("gradient"):
+    npts256 = 256 ** 3
+
+    def gradient_leg(name, engine_kw, bpu, note, shots=3):
         def wl():
             w = workloads.cfg4(1.0)
             w.nt = args.leg_nt or 1000
             return w
-        w, el, kern_us, info = run_leg(wl, local, 3, 1, grad=True)
-        r = roofline_entry("gradient", w, kern_us, 22.0, "hbm",
-                           "256^3 gradient shot: forward + store (20 B/update), adjoint + paired imaging "
-                           "(24 B/update); the forward-term store (%.1f GiB) streams through HBM"
-                           % (w.nt * int(np.prod(w.shape)) * 4 / 2.0 ** 30))
-        r["workload"] = "configs[3] grid, forward(save) + adjoint(imaging), %d time steps" % w.nt
-        r["Gpts_per_s_both_sweeps"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
-        r["ms_per_shot_gradient"] = round(1e3 * el / 3, 2)
+        w, el, kern_us, info = run_leg(wl, local, shots, 1, grad=True, engine_kw=engine_kw,
+                                       exchange=exchange if multi else None, barrier=rdzv.barrier if rdzv else None,
+                                       max_over_ranks=max_over_ranks if multi else None)
+        if rank != 0:
+            return
+        r = roofline_entry(name, w, kern_us, bpu, "hbm", note % (w.nt * int(np.prod(w.shape)) * 4 / 2.0 ** 30))
+        r["workload"] = "configs[3] grid, forward(save) + adjoint(imaging), %d time steps, %d shot(s) per GPU, " \
+                        "then the gradient all-reduce" % (w.nt, shots)
+        r["update_form"] = (engine_kw or {}).get("update_form", "standard")
+        r["n_gpus"] = world
+        r["Gpts_per_s_both_sweeps"] = round(world * shots * int(np.prod(w.shape)) * w.nt * 2 / el / 1e9, 1)
+        r["Gpts_per_s_both_sweeps_kernel_time"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
+        r["ms_per_shot_gradient"] = round(1e3 * el / shots, 2)
         r["kernel"] = info["kernel"]
-        legs["gradient"] = r
+        r["exchange"] = "none (one rank)" if not multi else \
+            "one rccl allreduce of the gradient accumulator after the %d shots, inside the timed region" % shots
+        r["rccl_ranks"] = info["rccl_ranks"]
+        r["allreduce_ms"] = info["allreduce_ms"]
+        r["allreduce_check"] = info["allreduce_check"]
+        legs[name] = r
+
+    # the gradient leg runs on every rank when there is an exchange to time (N > 1, or the forced rehearsal)
+    if args.leg == "gradient" or (args.leg == "all" and not grad and args.grid == 256 and (extra or multi)):
+        gradient_leg("gradient", None, 22.0,
+                     "256^3 gradient shot, STANDARD update form: forward + store (20 B/update), adjoint + paired "
+                     "imaging (24 B/update); the forward-term store (%.1f GiB) streams through HBM",
+                     shots=2 if multi else 3)
+    if want("gradient_increment"):
+        gradient_leg("gradient_increment", dict(update_form="increment"), 28.0,
+                     "256^3 gradient shot, INCREMENT update form (u, v = u - u_prev; the fp32 mode that meets 1e-5 end "
+                     "to end, profiles/r03_parity.json): forward + store 24 B/update, adjoint + imaging 32 B/update; "
+                     "four padded fields = 294 MB do not fit the Infinity Cache; store %.1f GiB", shots=2)
     if want("cfg2"):
         def wl():
             w = workloads.cfg2(1.0)
@@ -300,12 +360,68 @@ def main():
                            "so it moves FEWER bytes than the per-step algorithmic figure (traffic < algorithmic); the "
                            "fraction of the HBM peak is quoted for continuity only -- DESIGN.md s.4 states the LDS / "
                            "VALU / launch-boundary budget this kernel is measured against" % spl, steps_per_launch=spl)
-        r["workload"] = "configs[1]: 2-D 1024x1024 layered, 1 shot, %d steps, O(8) + absorbing border" % w.nt
+        r["workload"] = "configs[1]: 2-D 1024x1024 layered, 1 shot, %d steps, O(8) + absorbing border (sponge)" % w.nt
         r["us_per_time_step"] = round(step_us, 3)
         r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
         r["ms_per_shot"] = round(1e3 * el / 10, 3)
         r["kernel"] = info["kernel"]
         legs["cfg2"] = r
+    if want("cfg2_cpml"):
+        def wl():
+            w = workloads.cfg2(1.0)
+            if args.leg_nt:
+                w.nt = args.leg_nt
+            return w
+        w, el, step_us, info = run_leg(wl, local, 10, 2, engine_kw=dict(abc="cpml", pml_alpha_max=np.pi * 15.0))
+        spl = 4 if info["kernel"] == "step2d_fused" else 1
+        mv = 16 * 2 * (2 * w.npml * w.shape[0])  # psi, zeta read + written once per launch, both axes' borders
+        r = roofline_entry("cfg2_cpml", w, step_us * spl, BYTES_PER_UPDATE, "lds+valu (cache-resident fields)",
+                           "configs[1] with the CONVOLUTIONAL PML (npml %d) carried inside the fused kernel: %d time "
+                           "steps per launch, memory variables of the border in LDS beside the tile; the launch ends "
+                           "with its four corner tiles, which advance both borders' recursions (DESIGN.md s.4 CPML)"
+                           % (w.npml, spl), steps_per_launch=spl, extra_bytes=mv)
+        r["workload"] = "configs[1]: 2-D 1024x1024 layered, 1 shot, %d steps, O(8) + CPML npml %d" % (w.nt, w.npml)
+        r["us_per_time_step"] = round(step_us, 3)
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
+        r["ms_per_shot"] = round(1e3 * el / 10, 3)
+        r["kernel"] = info["kernel"]
+        legs["cfg2_cpml"] = r
+    if want("cpml3d"):
+        def wl():
+            w = workloads.cfg4(1.0, npml=16)
+            w.nt = args.leg_nt or 300
+            return w
+        w, el, step_us, info = run_leg(wl, local, 3, 1, engine_kw=dict(abc="cpml", pml_alpha_max=np.pi * 10.0))
+        mv = 16 * 3 * (2 * w.npml * w.shape[0] * w.shape[1])  # psi, zeta of three axes, read + written once per step
+        r = roofline_entry("cpml3d", w, step_us, BYTES_PER_UPDATE, "hbm",
+                           "256^3 forward with the CONVOLUTIONAL PML, npml %d: fields + 50 MB of memory variables = 271 "
+                           "MB do not fit the Infinity Cache (HBM regime: the undamped step kernel alone takes 48 us "
+                           "here); one time step = the step kernel with the x border's recursion in its lanes + 4 slab "
+                           "launches for the z and y borders; `kernel_avg_us` is the whole step" % w.npml,
+                           extra_bytes=mv)
+        r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
+        r["us_per_time_step"] = round(step_us, 3)
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
+        r["kernel"] = info["kernel"]
+        legs["cpml3d"] = r
+    for name, kw, bpu, what in (("fp64", dict(dtype="float64"), 32, "fp64 engine (step3d_stream<double>, 32 B/update)"),
+                                ("point", dict(kernel="point"), 16, "generic one-thread-per-point kernel (step_point)"),
+                                ("bf16", dict(store_dtype="bf16"), None, "bf16 forward-term store")):
+        if args.leg != name:
+            continue  # measurement-only legs (profiles/r03_*): never part of the default line
+        def wl():
+            w = workloads.cfg4(1.0)
+            w.nt = args.leg_nt or 300
+            return w
+        if name == "bf16":
+            w, el, kern_us, info = run_leg(wl, local, 2, 1, grad=True, engine_kw=kw)
+            bpu = (18 + 20) / 2.0
+        else:
+            w, el, kern_us, info = run_leg(wl, local, 3, 1, engine_kw=kw, dtype=kw.get("dtype"))
+        r = roofline_entry(name, w, kern_us, bpu, "hbm", "256^3, %s, %d time steps" % (what, w.nt))
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / kern_us / 1e3, 1)
+        r["kernel"] = info["kernel"]
+        legs[name] = r
 
     # N > 1: the 2-D configuration beside the headline (north_star: "a synthetic 1024^2 / 256^3 grid ... at 1, 2, 4
     # and 8 GPUs"): every rank runs configs[1] shots, barriers and the slowest rank's time go over the control plane.
@@ -330,7 +446,9 @@ def main():
                                 "ms_per_shot": round(1e3 * el2 / 10, 3), "us_per_time_step": round(step_us2, 3),
                                 "kernel": info2["kernel"], "exchange": "none (forward shots; barriers and the max over "
                                 "ranks go over the control plane)"}
-        except Exception as ex:  # noqa: BLE001 -- anything: the headline line must still be printed
+        except (RendezvousError, socket.timeout, OSError) as ex:
+            # only a control-plane failure is recoverable here (the leg is optional).  An FwiError -- a HIP or RCCL
+            # failure on the device -- is NOT caught: the process ends non-zero and the fault is investigated
             desync = True         # a rank may have missed a collective: no further control-plane traffic
             if rank == 0:
                 legs["cfg2"] = {"error": "%s: %s" % (type(ex).__name__, ex)}

@@ -72,3 +72,33 @@ def test_the_multi_rank_path_as_the_driver_launches_it_with_one_rank(gpu):
     leg = d["legs"]["cfg2"]
     assert "error" not in leg, leg
     assert leg["n_gpus"] == 1 and leg["kernel"] == "step2d_fused" and leg["Gpts_per_s"] > 50
+
+
+def test_the_gradient_leg_times_the_real_exchange_pattern_and_checks_the_sum(gpu):
+    """forward + store, adjoint + imaging per shot, then the ONE all-reduce of the accumulator --
+    rehearsed with one rank through the driver's launch line; the line carries the check g.g(after) = N^2 g.g(before)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, FWI_BENCH_FORCE_EXCHANGE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--leg", "gradient", "--leg-nt", "500"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    leg = d["legs"]["gradient"]
+    assert leg["rccl_ranks"] == 1 and "rccl allreduce" in leg["exchange"] and leg["allreduce_ms"] > 0
+    chk = leg["allreduce_check"]
+    assert chk["ok"] and chk["expected_ratio"] == 1.0 and chk["g_dot_g_before_sum"] > 0
+    assert leg["update_form"] == "standard" and leg["Gpts_per_s_both_sweeps"] > 20
+
+
+def test_the_cpml_legs_report_the_kernels_that_carry_the_border(gpu):
+    d = _run("--leg", "cfg2_cpml", "--leg-nt", "200")
+    leg = d["legs"]["cfg2_cpml"]
+    assert leg["kernel"] == "step2d_fused" and leg["us_per_time_step"] < 12.0  # (19.5 through the slab path)
+    assert leg["algorithmic_bytes_per_launch"] == 4 * 16 * 1024 ** 2 + 16 * 2 * 2 * 40 * 1024
+    d = _run("--leg", "cpml3d", "--leg-nt", "40")
+    assert d["legs"]["cpml3d"]["kernel"] == "step3d_stream" and d["legs"]["cpml3d"]["us_per_time_step"] > 0
