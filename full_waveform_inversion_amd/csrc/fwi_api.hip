@@ -64,6 +64,7 @@ struct fwi_ctx {
     bool pair3d = false;
     int pair_zc = 0, pair_tw = 256;
     int fused_skipd = -1;  // Fused2dArgs::skipd (FWI_FUSED2D_SKIPD, read at create)
+    int fused_ft = FUSED2D_TILE;  // interior tile edge of the fused 2-D kernel (fused2d_pick_tile; 64 with CPML / increment)
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     bool xpml = false;  // 3-D fp32 stream contexts: the x border's recursion runs inside the step kernel
@@ -556,14 +557,14 @@ struct Impl {
         if (ctx->fused2d) {
             // entries of the fused 2-D kernel: a point is injected by every tile whose EXTENDED region
             // holds it (each keeps a private copy of the halo) and sampled by the one tile owning it
-            constexpr int FT = FUSED2D_TILE;
+            const int FT = ctx->fused_ft;
             const int HL = (FUSED2D_STEPS * g.r + 3) / 4 * 4;  // as in step2d_fused
             const int ntx = (g.nx + FT - 1) / FT, ntz = (g.nz + FT - 1) / FT, ntile = ntx * ntz;
             struct Ent { int tile, lz, lx, col; unsigned char interior; };
             std::vector<Ent> ents;
             for (int i = 0; i < n; ++i) {
                 const int z = idx[(size_t)i * g.ndim], x = idx[(size_t)i * g.ndim + 1];
-                // HL < FT: only the owning tile and its direct neighbours can hold the point
+                // HL <= FT: only the owning tile and its direct neighbours can hold the point
                 for (int tz = std::max(0, z / FT - 1); tz <= std::min(ntz - 1, z / FT + 1); ++tz) {
                     if (z < tz * FT - HL || z >= tz * FT + FT + HL) continue;
                     for (int tx = std::max(0, x / FT - 1); tx <= std::min(ntx - 1, x / FT + 1); ++tx) {
@@ -773,6 +774,7 @@ struct Impl {
                 a.u_prev = (const float *)(ctx->inc ? sw.v : sw.f[sw.cur ^ 1]);  // increment form: v in / v out
                 a.inc = ctx->inc ? 1 : 0;
                 a.skipd = ctx->fused_skipd;
+                a.ft = ctx->fused_ft;
                 a.C = (const float *)ctx->C;
                 a.out_cur = (float *)spare[0];
                 a.out_prev = (float *)spare[1];
@@ -1556,6 +1558,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
                                 fused2d_cpml_supported(ctx->gd, cfg->npml) && !getenv("FWI_NO_FUSED2D_CPML");
     ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && (!ctx->cpml || cpml_in_launch) && !getenv("FWI_NO_FUSED2D") &&
                    (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
+    if (ctx->fused2d && !ctx->cpml && !ctx->inc) ctx->fused_ft = fused2d_pick_tile(ctx->gd);
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
     // =1 is the tuning / comparison hook)
     if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {

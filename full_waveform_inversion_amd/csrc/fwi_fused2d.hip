@@ -71,9 +71,13 @@ __device__ unsigned long long fwi_fused2d_stamps[4096 * 8];
 // u' = u + v'.  The tile then holds u twice (ping-pong: u' cannot overwrite u while neighbours still read it), v and C
 // = four LDS images (148 KB); HBM traffic is the same as in the standard form (u, v, C in; u, v out).
 // SKIPD: grids of more than one round of tiles (> 256) -- see the note at the damping profiles below.
+// Threads per workgroup by tile edge: 1024 for the 64- and 32-point tiles (24 x 96 / 16 x 64 groups), 512 for the
+// 16-point tile (12 x 48 = 576 groups).
+constexpr int fused2d_threads(int ft) { return ft >= 32 ? 1024 : 512; }
+
 template <int R, int KS, int FT, bool DAMP, bool SAVE_Q, bool IMAGE, bool INC, bool SKIPD = false>
-__global__ __launch_bounds__(1024) void step2d_fused(Fused2dArgs a, GridDesc g) {
-    constexpr int FNT = 1024;  // all modes fit the 128-VGPR cap of 1024 threads (68 - 102 VGPRs, no scratch)
+__global__ __launch_bounds__(fused2d_threads(FT)) void step2d_fused(Fused2dArgs a, GridDesc g) {
+    constexpr int FNT = fused2d_threads(FT);  // all modes fit the 128-VGPR cap of 1024 threads (68 - 102 VGPRs, no scratch)
     constexpr int HL = (KS * R + 3) / 4 * 4;  // halo cells per side (float4 aligned)
     constexpr int E = FT + 2 * HL;       // extended tile edge (rows and columns)
     constexpr int E4 = E / 4;            // float4 groups per row
@@ -355,35 +359,64 @@ extern "C" int fwi_debug_fused2d_stamps(unsigned long long *out, int n) {
 }
 #endif
 
-int fused2d_num_tiles(const GridDesc &g) {
-    return ((g.nx + FUSED2D_TILE - 1) / FUSED2D_TILE) * ((g.nz + FUSED2D_TILE - 1) / FUSED2D_TILE);
+int fused2d_num_tiles(const GridDesc &g, int ft) {
+    return ((g.nx + ft - 1) / ft) * ((g.nz + ft - 1) / ft);
+}
+
+int fused2d_pick_tile(const GridDesc &g) {
+    if (const char *e = getenv("FWI_FUSED2D_TILE")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 32 || v == 16) return v;
+    }
+    // cost of a launch ~ rounds of 256 workgroups x extended tile area (the halo is 4 r = 16 cells whatever the tile:
+    // a 32-point tile computes 4x its own area, a 16-point tile 9x -- worth it only while CUs would idle otherwise)
+    const int HL = (FUSED2D_STEPS * g.r + 3) / 4 * 4;
+    int best = FUSED2D_TILE;
+    int64_t best_cost = -1;
+    for (int ft : {64, 32, 16}) {
+        const int64_t tiles = fused2d_num_tiles(g, ft), e = ft + 2 * HL;
+        const int64_t cost = ((tiles + 255) / 256) * e * e;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = ft;
+        }
+    }
+    return best;
+}
+
+template <int R, int FT, bool DAMP, bool SKIPD>
+static hipError_t launch_fused_ft(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
+    constexpr int KS = FUSED2D_STEPS;
+    const dim3 grid(fused2d_num_tiles(g, FT));
+    if (a.inc) {
+        if (a.mode == 1)
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, true, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+        else if (a.mode == 2)
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, true, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+        else
+            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, true, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+    } else if (a.mode == 1)
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, false, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+    else if (a.mode == 2)
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, false, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+    else
+        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, false, SKIPD>), grid, dim3(fused2d_threads(FT)), 0, s, a, g);
+    return hipGetLastError();
 }
 
 template <int R, bool DAMP, bool SKIPD>
 static hipError_t launch_fused_r(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
-    constexpr int KS = FUSED2D_STEPS, FT = FUSED2D_TILE;
-    const dim3 grid(fused2d_num_tiles(g));
-    if (a.inc) {
-        if (a.mode == 1)
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
-        else if (a.mode == 2)
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
-        else
-            hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, true, SKIPD>), grid, dim3(1024), 0, s, a, g);
-    } else if (a.mode == 1)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, true, false, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
-    else if (a.mode == 2)
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, true, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
-    else
-        hipLaunchKernelGGL((step2d_fused<R, KS, FT, DAMP, false, false, false, SKIPD>), grid, dim3(1024), 0, s, a, g);
-    return hipGetLastError();
+    // (the increment form holds four LDS images: 64-point tiles only, the host never asks for less)
+    if (a.ft == 32 && !a.inc) return launch_fused_ft<R, 32, DAMP, SKIPD>(g, a, s);
+    if (a.ft == 16 && !a.inc) return launch_fused_ft<R, 16, DAMP, SKIPD>(g, a, s);
+    return launch_fused_ft<R, 64, DAMP, SKIPD>(g, a, s);
 }
 
 template <int R>
 static hipError_t launch_fused_d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s) {
     if (!a.damp) return launch_fused_r<R, false, false>(g, a, s);
     // more than one round of workgroups: interior tiles skip the damped update (FWI_FUSED2D_SKIPD=0 / 1 forces)
-    const bool skip = a.skipd >= 0 ? a.skipd != 0 : fused2d_num_tiles(g) > 256;
+    const bool skip = a.skipd >= 0 ? a.skipd != 0 : fused2d_num_tiles(g, a.ft ? a.ft : FUSED2D_TILE) > 256;
     return skip ? launch_fused_r<R, true, true>(g, a, s) : launch_fused_r<R, true, false>(g, a, s);
 }
 

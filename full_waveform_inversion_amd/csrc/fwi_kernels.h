@@ -165,7 +165,8 @@ bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, b
 
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch
-constexpr int FUSED2D_TILE = 64;   // interior tile edge (points); extended edge = TILE + 2 STEPS r
+constexpr int FUSED2D_TILE = 64;   // interior tile edge (points) of a grid that fills the chip with such tiles; extended
+                                   // edge = TILE + 2 STEPS r.  Smaller grids take 32- or 16-point tiles (Fused2dArgs::ft)
 
 struct Fused2dArgs {
     const float *u_cur, *u_prev, *C;   // padded inputs: u^n, u^{n-1}, dt^2 c^2
@@ -181,6 +182,7 @@ struct Fused2dArgs {
     int xcd_remap;                     // set by launch_fused2d: XCD-contiguous tile numbering
     int inc;                           // increment form: u_prev / out_prev are the v field in / out
     int skipd;                         // interior tiles skip the damped update: -1 = by tile count, 0 / 1 = forced
+    int ft;                            // interior tile edge: 64, 32 or 16 (0 = 64); fused2d_pick_tile()
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
     const int *inj_start, *inj_lz, *inj_lx, *inj_col;
     const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)
@@ -203,7 +205,10 @@ struct Fused2dArgs {
     float pml_dk[5], pml_dk1[5];
 };
 
-int fused2d_num_tiles(const GridDesc &g);
+int fused2d_num_tiles(const GridDesc &g, int ft = FUSED2D_TILE);
+// Tile edge that minimises rounds of workgroups x extended tile area (a 512^2 grid makes 64 tiles of 64^2 -- a
+// quarter of the chip -- but 256 of 32^2); FWI_FUSED2D_TILE overrides (tuning / tests).
+int fused2d_pick_tile(const GridDesc &g);
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
 // True when the fused kernel can carry the CPML of this grid: every border cell a tile sees lies deep inside that
 // tile's extended region or against the outside of the grid (conditions at fused2d_cpml_supported).

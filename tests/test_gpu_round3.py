@@ -85,3 +85,40 @@ def test_device_lbfgs_resumes_from_its_state_file(gpu, tmp_path):
     assert [r["evals"] for r in log2] == [r["evals"] for r in log_ref] == [r["evals"] for r in log3]
     assert abs(f2 - f_ref) <= 1e-5 * f_ref and abs(f3 - f_ref) <= 1e-4 * f_ref
     assert np.linalg.norm(x2 - x_ref) <= 1e-6 * np.linalg.norm(x_ref)
+
+
+@pytest.mark.parametrize("shape", [(133, 260), (70, 52)])
+def test_small_tile_instantiations_of_the_fused_2d_kernel_are_bit_identical(gpu, monkeypatch, shape):
+    """grids that make fewer than 256 tiles of 64^2 run step2d_fused on 32- or 16-point tiles.
+    Every tile size gives the BITS of step2d_tile -- seismograms, F^T r and gradient, duplicate source nodes, points on
+    tile seams -- and the default picks a small tile for these grids."""
+    rng = np.random.default_rng(21)
+    c = (1500.0 + 1500.0 * rng.random(shape)).astype(np.float32)
+    dt = 0.7 * fo.cfl_dt(float(c.max()), 5.0, 2, 8)
+    nt = 64
+    src = np.array([[shape[0] // 2, shape[1] // 2], [3, 3], [31, 32], [31, 32], [16, 15]])
+    rec = np.stack([rng.integers(0, s, 40) for s in shape], 1)
+    rec[:4] = [[15, 16], [32, 31], [shape[0] - 1, shape[1] - 1], [0, 0]]
+    wav = rng.standard_normal((nt, len(src))).astype(np.float32)
+    res = rng.standard_normal((nt, len(rec))).astype(np.float32)
+    out = {}
+    for name in ("tile", "64", "32", "16", "auto"):
+        monkeypatch.delenv("FWI_NO_FUSED2D", raising=False)
+        monkeypatch.delenv("FWI_FUSED2D_TILE", raising=False)
+        if name == "tile":
+            monkeypatch.setenv("FWI_NO_FUSED2D", "1")
+        elif name != "auto":
+            monkeypatch.setenv("FWI_FUSED2D_TILE", name)
+        with Engine(shape, 5.0, dt, nt, order=8, npml=10, sigma_max=900.0, kernel="stream") as e:
+            d = e.forward(c, (src, wav), rec, save=True)
+            a = e.adjoint(res)
+            out[name] = (e.kernel_name, d, a, e.gradient())
+    assert out["tile"][0] == "step2d_tile" and all(out[k][0] == "step2d_fused" for k in ("64", "32", "16", "auto"))
+    for k in ("64", "32", "16", "auto"):
+        assert np.array_equal(out[k][1], out["tile"][1]), k          # seismograms: the same bits
+        assert np.array_equal(out[k][2], out["tile"][2]), k          # F^T r
+        assert rel(out[k][3], out["tile"][3]) < 2e-6, k              # gradient: other pairing order of the imaging sum
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(b))
