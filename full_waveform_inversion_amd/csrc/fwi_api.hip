@@ -68,6 +68,8 @@ struct fwi_ctx {
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     bool xpml = false;  // 3-D fp32 stream contexts: the x border's recursion runs inside the step kernel
+    bool zpml_fwd = false, zpml_rev = false;  // ... and the z border's (forward / adjoint sweeps)
+    std::vector<double> pml_za, pml_zb;       // host copies of the z axis' CPML coefficients
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
@@ -291,6 +293,8 @@ struct Impl {
         a.npml = ctx->cfg.npml;
         a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
                                   ((double)ctx->cfg.npml * ctx->cfg.npml)) : T(0);
+        a.zp_on = 0;
+        a.zp_psi = a.zp_zeta = nullptr;
         a.xp_mode = 0;
         a.xp_psi = a.xp_zeta = nullptr;
         a.xp_a = a.xp_b = nullptr;
@@ -920,6 +924,16 @@ struct Impl {
                         a.xp_dk[k] = p.dk[k];
                         a.xp_dk1[k] = p.dk1[k];
                     }
+                    if (dn < 0 ? ctx->zpml_rev : ctx->zpml_fwd) {  // ... and the z border's on the z march
+                        axes = 2;
+                        a.zp_on = 1;
+                        a.zp_psi = p.psi[0];
+                        a.zp_zeta = p.zeta[0];
+                        for (int d = 1; d <= ctx->cfg.npml && d <= 64; ++d) {  // plane npml - d is d cells in
+                            a.zp_a[d - 1] = (T)ctx->pml_za[ctx->cfg.npml - d];
+                            a.zp_b[d - 1] = (T)ctx->pml_zb[ctx->cfg.npml - d];
+                        }
+                    }
                 }
                 HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream, axes));
                 HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream, axes));
@@ -1417,6 +1431,10 @@ int create_impl(fwi_ctx *ctx) {
                 pb[i] = std::exp(-(sig + alp) * c.dt);
                 pa[i] = sig > 0.0 ? sig / (sig + alp) * (pb[i] - 1.0) : 0.0;
             }
+            if (d == 0) {
+                ctx->pml_za = pa;
+                ctx->pml_zb = pb;
+            }
             int rc2;
             if (c.dtype == FWI_F32) {
                 if ((rc2 = upload_vec<float>(ctx, ctx->pml_a[d], pa)) || (rc2 = upload_vec<float>(ctx, ctx->pml_b[d], pb)))
@@ -1574,6 +1592,15 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     }
     ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !ctx->inc && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
+    if (ctx->xpml && cfg->npml <= 64 && !getenv("FWI_NO_STREAM_ZPML")) {
+        ctx->zpml_fwd = stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, false);
+        // the adjoint's form (two rings, 22 planes of LDS per thread column, ~100 registers parked in AGPRs) is slower
+        // than the slab launches it replaces (256^3: step kernel 65 -> 125 us against 28 us of slabs): opt-in only
+        ctx->zpml_rev = getenv("FWI_STREAM_ZPML_REV") && stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, true);
+    }
+    if (getenv("FWI_DEBUG_PML"))
+        fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d z-in-kernel fwd=%d rev=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
+                (int)ctx->fused2d, (int)ctx->xpml, (int)ctx->zpml_fwd, (int)ctx->zpml_rev, ctx->tune.ty, ctx->tune.zchunk);
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||

@@ -60,6 +60,12 @@ struct StepArgs {
     T *xp_psi, *xp_zeta;
     const T *xp_a, *xp_b;
     T xp_dk[5], xp_dk1[5];
+    // ... and of the z border on the z march (zp_on; same direction and weights as xp_*): memory variables in the slab
+    // kernels' layout (2 npml, ny, cx), coefficients BY DISTANCE into the border (entry d - 1 for a plane d cells in;
+    // the two borders are mirror images), kept in the kernel arguments so that they are scalar loads
+    int zp_on;
+    T *zp_psi, *zp_zeta;
+    T zp_a[64], zp_b[64];
 
     // Point operations fused into the step kernels (all nullptr / 0 = none).
     // Injection into u_next (and q_out): entries sorted by workgroup tile,
@@ -162,6 +168,8 @@ template <typename T>
 hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes = 7);
 // True when the 3-D stream kernel can carry the x border's recursion in its lanes (see step3d_stream, XP)
 bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32);
+// ... the z border's on its z march as well (ZP); `reverse`: the adjoint sweep (its rings need 4-row tiles)
+bool stream_zpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool reverse);
 
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch

@@ -275,8 +275,15 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 // comes through __shfl_up / __shfl_down (the 2 r-wide dependence of the border recursion never leaves the wave),
 // D u and E_x u from the x window the stencil has in registers anyway.  The memory variables are read and written
 // once per step by the lanes that own them -- no slab launches for this axis, no second pass over u' and q.
+// ZP (with XP: the same direction): the z border's recursion rides on the z march.  The queue runs r planes further
+// ahead (planes z - r .. z + 2r), so psi' of plane z + r -- which needs u(z .. z + 2r) -- is formed r planes before the
+// update of plane z reads psi'(z - r .. z + r); those 2r + 1 planes of psi' wait in a per-thread LDS ring (no thread
+// reads another's slot: no barrier).  The adjoint recursion keeps a zt' = alpha / a ring over z - r .. z + 2r and a
+// beta = a pt' ring over z - r .. z + r.  All of it sits under one wave-uniform test of the plane index -- planes
+// further than 2r from a border pay nothing but two clamped loads -- and holds no global LOAD (the pipelined loop keeps
+// its counted vmcnt).  Chunk seams must stay 2r planes clear of the borders (stream_zpml_supported).
 template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false,
-          bool QB = false, int XP = 0>
+          bool QB = false, int XP = 0, bool ZP = false>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk, int tw) {
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
@@ -405,14 +412,19 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     // into its own z queue, so the second request hits in the XCD's L2 instead of going back to
     // HBM ~4 planes later (measured at 512^3: traffic 1.235x algorithmic before).
     constexpr int NR = PF + 1;
-    constexpr int NQ = (2 * R + 1 + PF + NR - 1) / NR * NR;
+    constexpr int QE = ZP ? R : 0;  // planes the queue runs further ahead for the z border's recursion
+    constexpr int NQ = (2 * R + 1 + QE + PF + NR - 1) / NR * NR;
     constexpr int HPF = (NQ % (R + 1) == 0) ? R : PF;  // halo prefetch distance
     constexpr int NRH = HPF + 1;
     V zq[NQ];
+    // (ZP: the last prefetches would run one plane past the zero planes behind the grid: clamped onto the last one)
+    const int zlast = g.nz + HALO + LOOKAHEAD - 1;
 #pragma unroll
-    for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
+    for (int k = 0; k < 2 * R + QE + PF; ++k)
+        zq[k] = ldv<T>(a.u_cur + (int64_t)(ZP ? min(z0 - R + k, zlast) : z0 - R + k) * sz + poff);
     V up[NR], Cc[NR], halo[NRH][NH];
     V xps[XP ? NR : 1], xzt[XP ? NR : 1];  // psi / zeta (adjoint: pt / zt) of the x border, fetched like up / Cc
+    V zps[ZP ? NR : 1], zzt[ZP ? NR : 1];  // ... of the z border: psi(z + r) / zeta(z); adjoint pt(z + r) / zt(z + 2r)
     T edge[NR];
     // increment form: the pointwise operand is v^n (its own padded field) instead of u^{n-1}
     const T *const pw = INC ? a.v : a.u_prev;
@@ -434,6 +446,100 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
         for (int i = 0; i < NH; ++i) halo[p][i] = ldv<T>(a.u_cur + o + hoff[i]);
     }
 
+
+    // ---- z border in the march (ZP) ----------------------------------------------------------------------------
+    // rings: forward psi' over planes z - r .. z + r; adjoint alpha = a zt' over z - r .. z + 2r, beta = a pt' over
+    // z - r .. z + r.  Slot of plane p = (p - z0 + r) mod ring length; a thread touches only [.][ty][lane].
+    constexpr int NSA = ZP ? (XP == 2 ? 3 * R + 1 : 2 * R + 1) : 1, NSB = (ZP && XP == 2) ? 2 * R + 1 : 1;
+    __shared__ V zra[NSA][ZP ? TY : 1][ZP ? 64 : 1];
+    __shared__ V zrb[NSB][(ZP && XP == 2) ? TY : 1][(ZP && XP == 2) ? 64 : 1];
+    const unsigned zco = act ? coff : 0u;  // this thread's offset in a plane of the z memory variables (compact)
+    // coefficient of plane p by its distance into the border (kernel arguments: scalar loads), 0 off the border
+    auto zdist = [&](int p) { return (p >= 0 && p < g.nz) ? max(0, max(a.npml - p, p - (g.nz - 1 - a.npml))) : 0; };
+    auto zslab = [&](int p) { return p < a.npml ? max(p, 0) : (p >= g.nz - a.npml ? min(p, g.nz - 1) - (g.nz - 2 * a.npml) : 0); };
+    if constexpr (ZP) {
+        const V zero = {};
+        const bool lo_near = z0 < a.npml + 2 * R;  // (chunk seams are 2r clear of the borders: only chunk 0 starts inside one)
+        if (XP == 1) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) zra[(unsigned)r % NSA][ty][lane] = zero;  // planes z0 - r .. z0 - 1
+            // psi' of planes z0 .. z0 + r - 1 (the loop forms psi'(z + r) at plane z)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = z0 + r, d = zdist(p);
+                V v = zero;
+                if (lo_near && d > 0) {
+                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
+                    const V old = ldv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T du = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) du = fma(a.xp_dk1[k], zq[r + R + k].v[j] - zq[r + R - k].v[j], du);
+                        v.v[j] = fma(bv, old.v[j], av * du);
+                    }
+                    if (act) stv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco, v);
+                }
+                zra[(unsigned)(r + R) % NSA][ty][lane] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                zps[i] = ldv<T>(a.zp_psi + (int64_t)zslab(z0 + R + i) * cplane + zco);
+                zzt[i] = ldv<T>(a.zp_zeta + (int64_t)zslab(z0 + i) * cplane + zco);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                zra[(unsigned)r % NSA][ty][lane] = zero;
+                zrb[(unsigned)r % NSB][ty][lane] = zero;
+            }
+            // alpha of planes z0 .. z0 + 2r - 1, then beta of planes z0 .. z0 + r - 1
+#pragma unroll
+            for (int r = 0; r < 2 * R; ++r) {
+                const int p = z0 + r, d = zdist(p);
+                V v = zero;
+                if (lo_near && d > 0) {
+                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
+                    V zt = ldv<T>(a.zp_zeta + (int64_t)zslab(p) * cplane + zco);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        zt.v[j] = fma(bv, zt.v[j], zq[r + R].v[j]);
+                        v.v[j] = av * zt.v[j];
+                    }
+                    if (act) stv<T>(a.zp_zeta + (int64_t)zslab(p) * cplane + zco, zt);
+                }
+                zra[(unsigned)(r + R) % NSA][ty][lane] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = z0 + r, d = zdist(p);
+                V v = zero;
+                if (lo_near && d > 0) {
+                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
+                    V pt = ldv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco);
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) {
+                        T dw = T(0);  // D (mu + alpha)
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            const V ap = zra[(unsigned)(r + R + k) % NSA][ty][lane], am = zra[(unsigned)(r + R - k) % NSA][ty][lane];
+                            dw = fma(a.xp_dk1[k], (zq[r + R + k].v[j] + ap.v[j]) - (zq[r + R - k].v[j] + am.v[j]), dw);
+                        }
+                        pt.v[j] = bv * pt.v[j] - dw;
+                        v.v[j] = av * pt.v[j];
+                    }
+                    if (act) stv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco, pt);
+                }
+                zrb[(unsigned)(r + R) % NSB][ty][lane] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                zps[i] = ldv<T>(a.zp_psi + (int64_t)zslab(z0 + R + i) * cplane + zco);
+                zzt[i] = ldv<T>(a.zp_zeta + (int64_t)zslab(z0 + 2 * R + i) * cplane + zco);
+            }
+        }
+    }
+
     for (int zb = z0; zb < z1; zb += NQ) {
 #pragma unroll
         for (int ph = 0; ph < NQ; ++ph) {
@@ -452,7 +558,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
 
             // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
             const int64_t on = (int64_t)(z + PF) * sz;
-            zq[(ph + 2 * R + PF) % NQ] = ldv<T>(a.u_cur + (int64_t)(z + R + PF) * sz + poff);
+            zq[(ph + 2 * R + QE + PF) % NQ] =
+                ldv<T>(a.u_cur + (int64_t)(ZP ? min(z + R + QE + PF, zlast) : z + R + PF) * sz + poff);
             {
                 const int64_t oh = (int64_t)(z + HPF) * sz;
 #pragma unroll
@@ -467,6 +574,10 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                 const int64_t ox = (int64_t)min(z + PF, g.nz - 1) * xplane + xld;
                 xps[nxt] = ldv<T>(a.xp_psi + ox);
                 xzt[nxt] = ldv<T>(a.xp_zeta + ox);
+            }
+            if constexpr (ZP) {  // (planes off the border re-read slab plane 0: one cache line per wave)
+                zps[nxt] = ldv<T>(a.zp_psi + (int64_t)zslab(z + R + PF) * cplane + zco);
+                zzt[nxt] = ldv<T>(a.zp_zeta + (int64_t)zslab(z + (XP == 2 ? 2 * R : 0) + PF) * cplane + zco);
             }
             V qi, qi2, gi;
             if (IMAGE) {
@@ -492,9 +603,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             }
 #pragma unroll
             for (int j = 0; j < VL; ++j) X[HALO + j] = ctr.v[j];
-            V lap;
+            V lap, ezv;  // (ezv: the z second difference alone, for the z border's zeta)
 #pragma unroll
-            for (int j = 0; j < VL; ++j) lap.v[j] = T(0);
+            for (int j = 0; j < VL; ++j) lap.v[j] = ezv.v[j] = T(0);
 #pragma unroll
             for (int k = R; k >= 1; --k) {
                 const V ym = L[R + ty - k][HV + lane], yp = L[R + ty + k][HV + lane];
@@ -505,6 +616,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     T t = (X[HALO + j - k] + X[HALO + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
                     t = fma(T(-6), X[HALO + j], t);
                     lap.v[j] = fma(c, t, lap.v[j]);
+                    if (ZP && XP == 1) ezv.v[j] = fma(c, fma(T(-2), X[HALO + j], zm.v[j] + zp.v[j]), ezv.v[j]);
                 }
             }
             // x-border CPML: this lane's cells of the border recursion, neighbours through the wave
@@ -574,6 +686,108 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                 }
             }
 
+            // z-border CPML on the march (see the template comment): everything under one wave-uniform test
+            V zterm;
+#pragma unroll
+            for (int j = 0; j < VL; ++j) zterm.v[j] = T(0);
+            if constexpr (ZP) {
+                const unsigned s0 = (unsigned)(z - z0);  // ring slot of plane z - r (slot of plane p: p - z0 + r)
+                const bool near = XP == 1 ? (z < a.npml + R || z + R >= g.nz - a.npml)
+                                          : (z < a.npml + R || z + 2 * R >= g.nz - a.npml);
+                if (XP == 1) {
+                    const int pn = z + R;  // the plane whose psi' is formed now
+                    V pnv;
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) pnv.v[j] = T(0);
+                    const int dn = zdist(pn), dz = zdist(z);
+                    if (near && dn > 0) {
+                        const T an = a.zp_a[dn - 1], bn = a.zp_b[dn - 1];
+                        const V old = zps[cur];
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) {
+                            T du = T(0);
+#pragma unroll
+                            for (int k = 1; k <= R; ++k)
+                                du = fma(a.xp_dk1[k], zq[(ph + 2 * R + k) % NQ].v[j] - zq[(ph + 2 * R - k) % NQ].v[j], du);
+                            pnv.v[j] = fma(bn, old.v[j], an * du);
+                        }
+                        if (pn < z1 && act) stv<T>(a.zp_psi + (int64_t)zslab(pn) * cplane + zco, pnv);
+                    }
+                    zra[(s0 + 2 * R) % NSA][ty][lane] = pnv;
+                    if (near) {
+                        const T az = dz ? a.zp_a[max(dz, 1) - 1] : T(0), bz = dz ? a.zp_b[max(dz, 1) - 1] : T(0);
+                        V dp;
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) dp.v[j] = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            const V pp = zra[(s0 + R + k) % NSA][ty][lane], pm = zra[(s0 + R - k) % NSA][ty][lane];
+#pragma unroll
+                            for (int j = 0; j < VL; ++j) dp.v[j] = fma(a.xp_dk[k], pp.v[j] - pm.v[j], dp.v[j]);
+                        }
+                        V zn;
+                        const V zo = zzt[cur];
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) {
+                            zn.v[j] = fma(bz, zo.v[j], az * (ezv.v[j] + dp.v[j]));
+                            zterm.v[j] = dp.v[j] + zn.v[j];
+                        }
+                        if (dz > 0 && act) stv<T>(a.zp_zeta + (int64_t)zslab(z) * cplane + zco, zn);
+                    }
+                } else {
+                    const int p2 = z + 2 * R, pn = z + R;
+                    V al2, be;
+#pragma unroll
+                    for (int j = 0; j < VL; ++j) al2.v[j] = be.v[j] = T(0);
+                    const int d2 = zdist(p2), dn = zdist(pn);
+                    if (near && d2 > 0) {  // zt'(z + 2r) = b zt + mu;  alpha = a zt'
+                        const T a2 = a.zp_a[d2 - 1], b2 = a.zp_b[d2 - 1];
+                        V zt = zzt[cur];
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) {
+                            zt.v[j] = fma(b2, zt.v[j], zq[(ph + 3 * R) % NQ].v[j]);
+                            al2.v[j] = a2 * zt.v[j];
+                        }
+                        if (p2 < z1 && act) stv<T>(a.zp_zeta + (int64_t)zslab(p2) * cplane + zco, zt);
+                    }
+                    zra[(s0 + 3 * R) % NSA][ty][lane] = al2;
+                    if (near && dn > 0) {  // pt'(z + r) = b pt - D (mu + alpha);  beta = a pt'
+                        const T an = a.zp_a[dn - 1], bn = a.zp_b[dn - 1];
+                        V pt = zps[cur], dw;
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) dw.v[j] = T(0);
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            const V ap = zra[(s0 + 2 * R + k) % NSA][ty][lane], am = zra[(s0 + 2 * R - k) % NSA][ty][lane];
+#pragma unroll
+                            for (int j = 0; j < VL; ++j)
+                                dw.v[j] = fma(a.xp_dk1[k], (zq[(ph + 2 * R + k) % NQ].v[j] + ap.v[j]) -
+                                                               (zq[(ph + 2 * R - k) % NQ].v[j] + am.v[j]), dw.v[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < VL; ++j) {
+                            pt.v[j] = bn * pt.v[j] - dw.v[j];
+                            be.v[j] = an * pt.v[j];
+                        }
+                        if (pn < z1 && act) stv<T>(a.zp_psi + (int64_t)zslab(pn) * cplane + zco, pt);
+                    }
+                    zrb[(s0 + 2 * R) % NSB][ty][lane] = be;
+                    if (near) {  // term = E (alpha) - D (beta)
+                        const V a0 = zra[(s0 + R) % NSA][ty][lane];
+#pragma unroll
+                        for (int k = 1; k <= R; ++k) {
+                            const V ap = zra[(s0 + R + k) % NSA][ty][lane], am = zra[(s0 + R - k) % NSA][ty][lane];
+                            const V bp = zrb[(s0 + R + k) % NSB][ty][lane], bm = zrb[(s0 + R - k) % NSB][ty][lane];
+#pragma unroll
+                            for (int j = 0; j < VL; ++j) {
+                                zterm.v[j] = fma(a.ck[k], fma(T(-2), a0.v[j], ap.v[j] + am.v[j]), zterm.v[j]);
+                                zterm.v[j] = fma(-a.xp_dk[k], bp.v[j] - bm.v[j], zterm.v[j]);
+                            }
+                        }
+                    }
+                }
+            }
+
             V A = Axy, B = Bxy;
             if (DAMP) {
                 // d_z(z) from the plane index: a load here would be a VECTOR load (the compiler
@@ -593,7 +807,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             V q, un, vn;
 #pragma unroll
             for (int j = 0; j < VL; ++j) {
-                q.v[j] = XP ? Cc[cur].v[j] * (lap.v[j] + xterm.v[j]) : Cc[cur].v[j] * lap.v[j];
+                q.v[j] = XP ? Cc[cur].v[j] * (lap.v[j] + (ZP ? xterm.v[j] + zterm.v[j] : xterm.v[j]))
+                            : Cc[cur].v[j] * lap.v[j];
                 if (INC) {  // v' = A (B v + q), u' = u + v'
                     vn.v[j] = DAMP ? fma(B.v[j], up[cur].v[j], q.v[j]) * A.v[j] : up[cur].v[j] + q.v[j];
                     un.v[j] = X[HALO + j] + vn.v[j];
@@ -793,6 +1008,18 @@ bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, b
     return tw >= npml + g.r && g.nx - (nxt - 1) * tw >= npml + g.r;
 }
 
+bool stream_zpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool reverse) {
+    // (on top of stream_xpml_supported) chunk seams 2 r planes clear of the borders: a chunk that starts or ends inside
+    // a border's reach would need its neighbour's psi'.  The adjoint's rings fit the LDS with 4-row tiles only.
+    const int r = g.r, zc = t.zchunk > 0 ? t.zchunk : g.nz;
+    (void)reverse;
+    if (g.nz <= 2 * (npml + 2 * r)) return false;
+    if (t.ty != 4) return false;  // 8-row tiles: the rings' registers spill (forward) / their LDS overflows (adjoint)
+    for (int zb = zc; zb < g.nz; zb += zc)
+        if (zb < npml + 2 * r || zb > g.nz - npml - 2 * r) return false;
+    return true;
+}
+
 StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
     const int full_x = is_f32 ? 256 : 128, vl = is_f32 ? 4 : 2;
     // 3-D: split nx into equal x tiles (multiples of the lane vector) rather than full ones plus a remainder
@@ -898,6 +1125,31 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
         }
     }
     if constexpr (std::is_same<T, float>::value && R == 4 && !DAMP) {
+        if constexpr (TY == 4) {  // (4-row tiles only: with 8 rows the rings' registers spill / the adjoint's LDS overflows)
+            if (a.xp_mode == 1 && a.zp_on) {  // x border in the lanes + z border on the march, forward recursion
+                if (a.q_out)
+                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1, true>), grid, block,
+                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+                else
+                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 1, true>), grid, block,
+                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+                return hipGetLastError();
+            }
+        }
+        if constexpr (TY == 4) {
+            if (a.xp_mode == 2 && a.zp_on) {
+                if (a.q_in && a.q_in2)
+                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 2, true>), grid, block,
+                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+                else if (a.q_in)
+                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 2, true>), grid, block,
+                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+                else
+                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 2, true>), grid, block,
+                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+                return hipGetLastError();
+            }
+        }
         if (a.xp_mode == 1) {  // x-border CPML in the lanes, forward recursion
             if (a.q_out)
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1>), grid, block, 0, s,

@@ -36,6 +36,10 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((20, 18, 300), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {}),           # two x tiles of 152 / 148 columns
     ((24, 16, 256), 8, 16, 20.0, "float32", TOL32, "step3d_stream", {}),          # full 256-column tiles (FULL path)
     ((30, 24, 40), 8, 12, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 7}), # several z chunks per tile
+    # ... and their z border on the z march as well (stream_zpml_supported: 4-row tiles, chunk seams clear of the borders)
+    ((64, 20, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": 32}),   # a seam between the two borders
+    ((56, 18, 44), 8, 8, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 56}),    # one chunk holds both
+    ((70, 17, 40), 8, 12, 25.0, "float32", TOL32, "step3d_stream", {"zchunk": 35, "ckpt_interval": 20}),
     # grids the fused 2-D kernel takes WITH the border recursion inside the launch (fused2d_cpml_supported): 70 steps
     # = 68 in 4-step launches + 2 through the slab path, on the same memory variables
     ((192, 256), 8, 40, 40.0, "float32", TOL32, "step2d_fused", {}),            # cfg2's border width, 48-cell images
@@ -71,6 +75,14 @@ def test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw):
         dg2 = e.forward(None, (src, wav), rec, save=False)  # the memory variables restart from zero
     assert np.array_equal(dg, dg2) or rel(dg2, dg) < 1e-6
     assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (rel(dg, d), rel(ag, a), rel(gg, g))
+
+
+@pytest.mark.parametrize("shape,zchunk", [((64, 20, 48), 32), ((56, 18, 44), 56)])
+def test_cpml_z_border_on_the_march_in_the_adjoint_sweep_too(gpu, monkeypatch, shape, zchunk):
+    """The adjoint form of the in-kernel z border (two LDS rings) is built and correct but SLOWER than the slab
+    launches it replaces (DESIGN.md s.4 CPML), so it is opt-in: FWI_STREAM_ZPML_REV=1.  Same bar as everything else."""
+    monkeypatch.setenv("FWI_STREAM_ZPML_REV", "1")
+    test_cpml_vs_oracle(gpu, shape, 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": zchunk})
 
 
 @pytest.mark.parametrize("shape", [(40, 36, 44), (60, 52)])
