@@ -68,6 +68,7 @@ struct fwi_ctx {
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
     bool xpml = false;  // 3-D fp32 stream contexts: the x border's recursion runs inside the step kernel
+    int pml_lines = 0;  // axes (z = 1, y = 2) whose border runs as one line launch per step (pml_line_axes)
     bool zpml_fwd = false, zpml_rev = false;  // ... and the z border's (forward / adjoint sweeps)
     std::vector<double> pml_za, pml_zb;       // host copies of the z axis' CPML coefficients
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
@@ -935,10 +936,17 @@ struct Impl {
                         }
                     }
                 }
-                HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream, axes));
-                HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream, axes));
+                // z / y borders the step kernel does not carry: one line launch per axis after it (all three phases;
+                // fwi_pml.hip, pml_line), the slab phases for whatever is left
+                const int lines = axes & ctx->pml_lines;
+                axes &= ~lines;
+                if (axes) {
+                    HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream, axes));
+                    HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream, axes));
+                }
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
-                HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream, axes));  // ... and their term joins u' (and q)
+                if (axes) HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream, axes));  // their term joins u' (and q)
+                if (lines) HIPCHK(ctx, launch_pml_lines<T>(g, p, dn < 0, ctx->stream, lines));
             } else {
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
             }
@@ -1592,15 +1600,20 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     }
     ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !ctx->inc && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
-    if (ctx->xpml && cfg->npml <= 64 && !getenv("FWI_NO_STREAM_ZPML")) {
+    // The z border on the z march is opt-in (FWI_STREAM_ZPML=1) since the line launches exist: it saves the z line
+    // launch (~21 us at 256^3 / npml 16) but costs the step kernel more than that (58 -> 84 us: the border planes all
+    // fall to the first and last z chunk, whose workgroups then decide the launch): forward 106 against 99 us/step.
+    if (ctx->xpml && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
         ctx->zpml_fwd = stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, false);
         // the adjoint's form (two rings, 22 planes of LDS per thread column, ~100 registers parked in AGPRs) is slower
         // than the slab launches it replaces (256^3: step kernel 65 -> 125 us against 28 us of slabs): opt-in only
         ctx->zpml_rev = getenv("FWI_STREAM_ZPML_REV") && stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, true);
     }
+    if (ctx->cpml) ctx->pml_lines = pml_line_axes(ctx->gd, cfg->npml);
     if (getenv("FWI_DEBUG_PML"))
-        fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d z-in-kernel fwd=%d rev=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
-                (int)ctx->fused2d, (int)ctx->xpml, (int)ctx->zpml_fwd, (int)ctx->zpml_rev, ctx->tune.ty, ctx->tune.zchunk);
+        fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d z-in-kernel fwd=%d rev=%d line-axes=%d (ty %d zchunk %d)\n",
+                (int)ctx->cpml, (int)ctx->fused2d, (int)ctx->xpml, (int)ctx->zpml_fwd, (int)ctx->zpml_rev, ctx->pml_lines,
+                ctx->tune.ty, ctx->tune.zchunk);
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||

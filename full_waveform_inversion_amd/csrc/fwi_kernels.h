@@ -166,6 +166,12 @@ struct PmlArgs {
 // `axes`: bit d set = run axis d (z = 1, y = 2, x = 4); an axis the step kernel carries itself is left out
 template <typename T>
 hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes = 7);
+// Line form of the z / y border (3-D): ONE launch per axis after the step kernel does all three phases (a thread
+// marches its line through the border with the field and the new memory variables in register windows).
+// pml_line_axes: the axes (z = 1, y = 2) it takes for this grid -- the slab phases are then run without them.
+int pml_line_axes(const GridDesc &g, int npml);
+template <typename T>
+hipError_t launch_pml_lines(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes);
 // True when the 3-D stream kernel can carry the x border's recursion in its lanes (see step3d_stream, XP)
 bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32);
 // ... the z border's on its z march as well (ZP); `reverse`: the adjoint sweep (its rings need 4-row tiles)

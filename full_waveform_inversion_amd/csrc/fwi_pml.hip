@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "fwi_kernels.h"
@@ -392,6 +393,362 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LINE form of the z / y border (3-D): one launch per axis and time step instead of three slab passes.
+//
+// Along its own axis the border recursion is one-dimensional: psi'(i), zeta'(i) and the term of cell i need the field
+// and the memory variables of the SAME (other two coordinates) line only.  So a thread owns one 16-byte lane of x at a
+// fixed other coordinate and marches along the axis through the border and the r cells its term reaches, in blocks of
+// four cells: the field values of the line sit in a register window (every u is loaded once instead of 2r + 1 times),
+// the new psi' (adjoint: alpha = a zt', beta = a pt') in a second one -- they are never re-read from memory, which is
+// what forced the slab form into three passes -- and every memory variable is read once and written once per step,
+// with streaming hints: at 256^3 the six of them (50 MB) are what pushed the wavefields out of the Infinity Cache.
+// The inputs of block k + 1 are in flight while block k is computed.  All accesses are 16 bytes per lane along x.
+// Off the border a = b = 0 make psi' = zeta' = 0 by themselves, so one loop body serves the low border, the high
+// border and the case of the two (nearly) meeting (n < 2 npml + 3 r: one segment over the whole axis); loads are clamped
+// instead of branched around, stores predicated.  Runs AFTER the step kernel: reads u^n (adjoint: the newest mu) and
+// the old memory variables, adds C * term to u' (v', q).
+#ifndef PML_LINE_BS1
+#define PML_LINE_BS1 8
+#endif
+template <typename T, int R, int D, bool REV, bool NT, int VL>
+__global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
+    // cells per block = the loads a thread keeps in flight (5-7 per cell): 4-byte lanes take twice the cells to have
+    // the same bytes per wave on the way while a block is computed, and half the round trips per line
+    constexpr int BS = VL == 1 ? PML_LINE_BS1 : 4;
+    constexpr int W = (2 * R + BS - 1) / BS * BS;  // warm-up cells ahead of the segment (whole blocks)
+    constexpr int NU = BS + 3 * R, NP = BS + 2 * R;
+    constexpr int MAXC = 192;                      // rows of the coefficient tables (launch_pml_lines checks)
+    using V = vecn<T, VL>;
+    typedef T ntv_t __attribute__((ext_vector_type(VL > 1 ? VL : 2)));
+    static_assert(D == 0 || D == 1, "z or y axis");
+    __shared__ T ca[MAXC], cb[MAXC];
+
+    const int n = D == 0 ? g.nz : g.ny, npml = p.npml;
+    // (the low segment computes memory variables up to 2r rows past its end -- all zero off the border, but not if the
+    // high border begins there: then one thread takes the whole axis, in order)
+    const bool merged = n < 2 * npml + 3 * R;
+    const int seg = blockIdx.z;
+    const int ib = (merged || seg == 0) ? 0 : n - npml - R;
+    const int ie = (merged || seg == 1) ? n : npml + R;
+    const int is = ib - W;                // first (warm-up) block
+    const int c0 = is - R;                // grid row of table entry 0
+    const int nrows = (ie - is + BS - 1) / BS * BS + 3 * R + BS;
+    for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < nrows && i < MAXC; i += blockDim.x * blockDim.y) {
+        // (a segment sees its OWN border only: its last block may look a few rows into the other one, which the
+        // other segment's threads are advancing at the same time)
+        const int j = c0 + i;
+        const bool in = j >= 0 && j < n && (merged ? (j < npml || j >= n - npml) : seg == 0 ? j < npml : j >= n - npml);
+        ca[i] = in ? p.a[D][j] : T(0);
+        cb[i] = in ? p.b[D][j] : T(0);
+    }
+    __syncthreads();
+
+    const int xv = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y * blockDim.y + threadIdx.y;  // the other coordinate: y (D = 0) or z (D = 1)
+    const int no = D == 0 ? g.ny : g.nz;
+    const bool act = VL * xv < g.cx && o < no;
+    const int x = act ? VL * xv : 0, oc = act ? o : 0;
+    const int nslab = min(n, 2 * npml);
+    const int64_t gs = D == 0 ? g.sz : g.sy;                                          // field stride along the axis
+    const int64_t fbase = g.off0 + (int64_t)oc * (D == 0 ? g.sy : g.sz) + x;          // padded index of row 0
+    const int64_t ast = D == 0 ? (int64_t)g.ny * g.cx : g.cx;                         // memory-variable stride
+    const int64_t abase = D == 0 ? (int64_t)oc * g.cx + x : (int64_t)oc * nslab * g.cx + x;
+    const int64_t qst = D == 0 ? (int64_t)g.ny * g.cx : g.cx;                         // compact stride (q)
+    const int64_t qbase = D == 0 ? (int64_t)oc * g.cx + x : (int64_t)oc * g.ny * g.cx + x;
+    T *const m0 = REV ? p.zeta[D] : p.psi[D];   // the variable advanced first:  psi / zt
+    T *const m1 = REV ? p.psi[D] : p.zeta[D];   // ... and second:               zeta / pt
+
+    auto ldf = [&](const T *f, int j) {  // field row j, clamped into the zero halo
+        return ldn<T, VL>(f + fbase + (int64_t)min(max(j, -HALO), n - 1 + HALO) * gs);
+    };
+    auto slab = [&](int j) {  // slab plane of grid row j (clamped: the value is multiplied by b = 0 off the border)
+        const int jc = min(max(j, 0), n - 1);
+        return (n <= 2 * npml || jc < npml) ? min(jc, nslab - 1) : max(jc - (n - nslab), 0);
+    };
+    auto ldm = [&](const T *m, int j) {
+        const T *q = m + abase + (int64_t)slab(j) * ast;
+        if constexpr (NT && VL > 1) {
+            const ntv_t v = __builtin_nontemporal_load(reinterpret_cast<const ntv_t *>(q));
+            V r;
+#pragma unroll
+            for (int t = 0; t < VL; ++t) r.v[t] = v[t];
+            return r;
+        } else if constexpr (NT) {
+            V r;
+            r.v[0] = __builtin_nontemporal_load(q);
+            return r;
+        } else {
+            return ldn<T, VL>(q);
+        }
+    };
+    auto stm = [&](T *m, int j, const V &v) {
+        T *q = m + abase + (int64_t)slab(j) * ast;
+        if constexpr (NT && VL > 1) {
+            ntv_t w;
+#pragma unroll
+            for (int t = 0; t < VL; ++t) w[t] = v.v[t];
+            __builtin_nontemporal_store(w, reinterpret_cast<ntv_t *>(q));
+        } else if constexpr (NT) {
+            __builtin_nontemporal_store(v.v[0], q);
+        } else {
+            stn<T, VL>(q, v);
+        }
+    };
+    auto inb = [&](int j) {  // border rows this segment owns (and stores)
+        return j >= 0 && j < n && (merged ? (j < npml || j >= n - npml) : seg == 0 ? j < npml : j >= n - npml);
+    };
+
+    struct In {
+        V un[BS];  // new field rows of the window
+        V o0[BS];  // old values of the variable advanced first, at its new rows
+        V o1[BS];  // ... of the second
+        V c[BS], up[BS], vv[BS], qq[BS];  // C, u', v', q of the block's own rows
+    };
+    // rows whose inputs a block at i0 needs (REV: zt sits 2r ahead like the field, pt r ahead; forward: psi r ahead,
+    // zeta at the block's own rows)
+    auto issue = [&](int i0, In &in) {
+        const bool out = i0 >= ib;
+#pragma unroll
+        for (int t = 0; t < BS; ++t) {
+            in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
+            in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
+            in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
+            const int jr = out ? min(i0 + t, ie - 1) : ib;  // (warm-up blocks re-read one row: cache hits)
+            in.c[t] = ldf(p.C, jr);
+            in.up[t] = ldf(p.u_next, jr);
+            if (p.v) in.vv[t] = ldf(p.v, jr);
+            if (p.q_out) in.qq[t] = ldn<T, VL>(p.q_out + qbase + (int64_t)min(max(jr, 0), n - 1) * qst);
+        }
+    };
+
+    V Uw[NU];  // forward: u rows i0 - r .. i0 + BS - 1 + 2r.   adjoint: alpha over the same rows
+    V Pw[NP];  // forward: psi' rows i0 - r .. i0 + BS - 1 + r.  adjoint: beta
+    V Mw[REV ? NP : 1];  // adjoint: mu rows i0 .. i0 + BS - 1 + 2r
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+        for (int t = 0; t < VL; ++t) Uw[k].v[t] = T(0);
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int t = 0; t < VL; ++t) Pw[k].v[t] = T(0);
+    if (!REV) {
+#pragma unroll
+        for (int k = 0; k < 3 * R; ++k) Uw[k] = ldf(p.u_cur, is - R + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) Mw[k] = ldf(p.u_cur, is + k);
+    }
+    In nxt;
+    issue(is, nxt);
+    for (int i0 = is; i0 < ie; i0 += BS) {
+        const In cur = nxt;
+        issue(i0 + BS, nxt);
+        const int tb = i0 - c0;  // table entry of row i0
+        const bool out = i0 >= ib;
+        if (!REV) {
+#pragma unroll
+            for (int t = 0; t < BS; ++t) Uw[3 * R + t] = cur.un[t];
+            // psi'(j) = b psi + a D u, j = i0 + r + t
+#pragma unroll
+            for (int t = 0; t < BS; ++t) {
+                const int j = i0 + R + t;
+                const T av = ca[tb + R + t], bv = cb[tb + R + t];
+                V v;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    T du = T(0);
+#pragma unroll
+                    for (int k = 1; k <= R; ++k) du = fma(p.dk1[k], Uw[2 * R + t + k].v[q] - Uw[2 * R + t - k].v[q], du);
+                    v.v[q] = fma(bv, cur.o0[t].v[q], av * du);
+                }
+                Pw[2 * R + t] = v;
+                if (act && inb(j)) stm(m0, j, v);
+            }
+            // zeta'(i) = b zeta + a (E u + D psi');  term = D psi' + zeta'   (warm-up blocks: nothing to form)
+            if (out)
+#pragma unroll
+            for (int t = 0; t < BS; ++t) {
+                const int i = i0 + t;
+                const T av = ca[tb + t], bv = cb[tb + t];
+                V zn, add;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    T dp = T(0), e2 = T(0);
+#pragma unroll
+                    for (int k = 1; k <= R; ++k) {
+                        dp = fma(p.dk[k], Pw[R + t + k].v[q] - Pw[R + t - k].v[q], dp);
+                        e2 = fma(p.ck[k], fma(T(-2), Uw[R + t].v[q], Uw[R + t + k].v[q] + Uw[R + t - k].v[q]), e2);
+                    }
+                    zn.v[q] = fma(bv, cur.o1[t].v[q], av * (e2 + dp));
+                    add.v[q] = cur.c[t].v[q] * (dp + zn.v[q]);
+                }
+                const bool row = act && out && i < ie;
+                if (row && inb(i)) stm(m1, i, zn);
+                if (row) {
+                    V un = cur.up[t];
+#pragma unroll
+                    for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
+                    stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
+                    if (p.v) {
+                        V w = cur.vv[t];
+#pragma unroll
+                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
+                        stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
+                    }
+                    if (p.q_out) {
+                        V w = cur.qq[t];
+#pragma unroll
+                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
+                        stn<T, VL>(p.q_out + qbase + (int64_t)i * qst, w);
+                    }
+                }
+            }
+        } else {
+            // zt'(j) = b zt + mu(j), alpha = a zt',  j = i0 + 2r + t
+#pragma unroll
+            for (int t = 0; t < BS; ++t) {
+                const int j = i0 + 2 * R + t;
+                Mw[2 * R + t] = cur.un[t];
+                const T av = ca[tb + 2 * R + t], bv = cb[tb + 2 * R + t];
+                V zt;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    zt.v[q] = fma(bv, cur.o0[t].v[q], cur.un[t].v[q]);
+                    Uw[3 * R + t].v[q] = av * zt.v[q];
+                }
+                if (act && inb(j)) stm(m0, j, zt);
+            }
+            // pt'(j) = b pt - D (mu + alpha), beta = a pt',  j = i0 + r + t
+#pragma unroll
+            for (int t = 0; t < BS; ++t) {
+                const int j = i0 + R + t;
+                const T av = ca[tb + R + t], bv = cb[tb + R + t];
+                V pt;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    T d = T(0);
+                    // (mu rows start at i0: row j - k is entry r + t - k >= 0)
+#pragma unroll
+                    for (int k = 1; k <= R; ++k)
+                        d = fma(p.dk1[k], (Mw[R + t + k].v[q] - Mw[R + t - k].v[q]) +
+                                              (Uw[2 * R + t + k].v[q] - Uw[2 * R + t - k].v[q]), d);
+                    pt.v[q] = bv * cur.o1[t].v[q] - d;
+                    Pw[2 * R + t].v[q] = av * pt.v[q];
+                }
+                if (act && inb(j)) stm(m1, j, pt);
+            }
+            // term(i) = E alpha - D beta
+            if (out)
+#pragma unroll
+            for (int t = 0; t < BS; ++t) {
+                const int i = i0 + t;
+                V add;
+#pragma unroll
+                for (int q = 0; q < VL; ++q) {
+                    T e2 = T(0), db = T(0);
+#pragma unroll
+                    for (int k = 1; k <= R; ++k) {
+                        e2 = fma(p.ck[k], fma(T(-2), Uw[R + t].v[q], Uw[R + t + k].v[q] + Uw[R + t - k].v[q]), e2);
+                        db = fma(p.dk[k], Pw[R + t + k].v[q] - Pw[R + t - k].v[q], db);
+                    }
+                    add.v[q] = cur.c[t].v[q] * (e2 - db);
+                }
+                if (act && out && i < ie) {
+                    V un = cur.up[t];
+#pragma unroll
+                    for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
+                    stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
+                    if (p.v) {
+                        V w = cur.vv[t];
+#pragma unroll
+                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
+                        stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
+                    }
+                    if (p.q_out) {
+                        V w = cur.qq[t];
+#pragma unroll
+                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
+                        stn<T, VL>(p.q_out + qbase + (int64_t)i * qst, w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NP - BS; ++k) Mw[k] = Mw[k + BS];
+        }
+        // slide the windows by one block
+#pragma unroll
+        for (int k = 0; k < NU - BS; ++k) Uw[k] = Uw[k + BS];
+#pragma unroll
+        for (int k = 0; k < NP - BS; ++k) Pw[k] = Pw[k + BS];
+    }
+}
+
+// Axes (bit mask: z = 1, y = 2) the line form takes for this grid; the slab phases keep the rest.
+// (table rows for the largest block size, PML_LINE_BS1)
+int pml_line_axes(const GridDesc &g, int npml) {
+    const bool off = getenv("FWI_NO_PML_LINES") != nullptr;  // (read per context: the tests switch it)
+    if (off || g.ndim != 3 || npml < 1) return 0;
+    int axes = 0;
+    const int nd[2] = {g.nz, g.ny};
+    for (int d = 0; d < 2; ++d) {
+        constexpr int B = PML_LINE_BS1;
+        const int n = nd[d], r = g.r, W = (2 * r + B - 1) / B * B;
+        const int len = n < 2 * npml + 3 * r ? n : npml + r;            // cells of a segment
+        const int rows = (len + W + B - 1) / B * B + 3 * r + B;         // table rows the kernel fills
+        if (rows <= 192 && n >= 1) axes |= 1 << d;
+    }
+    return axes;
+}
+
+template <typename T, int R, int D, int VL>
+static void launch_pml_line_vl(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
+    static const bool plain = getenv("FWI_PML_LINES_PLAIN") != nullptr;  // A/B hook: no streaming hints
+    const int n = D == 0 ? g.nz : g.ny, no = D == 0 ? g.ny : g.nz;
+    const int nxv = g.cx / VL;
+    const int bx = nxv <= 16 ? 16 : nxv <= 32 ? 32 : 64, by = 256 / bx;
+    const dim3 block(bx, by);
+    const dim3 grid((nxv + bx - 1) / bx, (no + by - 1) / by, n < 2 * p.npml + 3 * R ? 1 : 2);
+    if (reverse) {
+        if (plain) hipLaunchKernelGGL((pml_line<T, R, D, true, false, VL>), grid, block, 0, s, p, g);
+        else hipLaunchKernelGGL((pml_line<T, R, D, true, true, VL>), grid, block, 0, s, p, g);
+    } else {
+        if (plain) hipLaunchKernelGGL((pml_line<T, R, D, false, false, VL>), grid, block, 0, s, p, g);
+        else hipLaunchKernelGGL((pml_line<T, R, D, false, true, VL>), grid, block, 0, s, p, g);
+    }
+}
+
+// Lane width: the march is a serial chain per thread (blocks x (arithmetic + one round trip)), so what counts is how
+// many waves share it -- 16-byte lanes make 512 waves at 256^3 (half the SIMDs idle), 4-byte lanes 2048.
+template <typename T, int R, int D>
+static void launch_pml_line_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
+    static const int vl_env = getenv("FWI_PML_LINES_VL") ? atoi(getenv("FWI_PML_LINES_VL")) : 0;
+    constexpr int VMAX = (int)(16 / sizeof(T));
+    const int vl = vl_env ? vl_env : 2;  // (256^3 / npml 16, forward, us/step: 4-byte lanes 103-106, 8-byte 99-101, 16-byte 110)
+    if (vl >= VMAX) launch_pml_line_vl<T, R, D, VMAX>(g, p, reverse, s);
+    else if (vl == 2) launch_pml_line_vl<T, R, D, 2>(g, p, reverse, s);
+    else launch_pml_line_vl<T, R, D, 1>(g, p, reverse, s);
+}
+
+template <typename T, int R>
+static hipError_t launch_pml_lines_r(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes) {
+    if (axes & 1) launch_pml_line_axis<T, R, 0>(g, p, reverse, s);
+    if (axes & 2) launch_pml_line_axis<T, R, 1>(g, p, reverse, s);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_pml_lines(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes) {
+    switch (g.r) {
+        case 1: return launch_pml_lines_r<T, 1>(g, p, reverse, s, axes);
+        case 2: return launch_pml_lines_r<T, 2>(g, p, reverse, s, axes);
+        default: return launch_pml_lines_r<T, 4>(g, p, reverse, s, axes);
+    }
+}
+template hipError_t launch_pml_lines<float>(const GridDesc &, const PmlArgs<float> &, int, hipStream_t, int);
+template hipError_t launch_pml_lines<double>(const GridDesc &, const PmlArgs<double> &, int, hipStream_t, int);
 
 template <typename T, int R, int D, int PHASE>
 static void launch_pml_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {

@@ -36,10 +36,18 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((20, 18, 300), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {}),           # two x tiles of 152 / 148 columns
     ((24, 16, 256), 8, 16, 20.0, "float32", TOL32, "step3d_stream", {}),          # full 256-column tiles (FULL path)
     ((30, 24, 40), 8, 12, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 7}), # several z chunks per tile
-    # ... and their z border on the z march as well (stream_zpml_supported: 4-row tiles, chunk seams clear of the borders)
+    # grids on which the z border can ride on the z march as well (stream_zpml_supported; opt-in, see
+    # test_cpml_z_border_on_the_march) -- by default their z and y borders run as line launches
     ((64, 20, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": 32}),   # a seam between the two borders
     ((56, 18, 44), 8, 8, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 56}),    # one chunk holds both
     ((70, 17, 40), 8, 12, 25.0, "float32", TOL32, "step3d_stream", {"zchunk": 35, "ckpt_interval": 20}),
+    # line launches (fwi_pml.hip, pml_line): long borders (several blocks per line), O(2) / O(4) windows, fp64 lanes,
+    # borders that nearly meet (one merged segment per line: n < 2 npml + 3 r), the point kernel around them
+    ((72, 40, 36), 8, 20, 25.0, "float32", TOL32, "step3d_stream", {}),
+    ((31, 27, 40), 4, 9, 10.0, "float64", TOL64, "step3d_stream", {}),
+    ((26, 23, 33), 2, 7, 0.0, "float32", TOL32, "step3d_stream", {}),
+    ((34, 33, 32), 8, 11, 30.0, "float64", TOL64, "step_point", {"update_form": "increment"}),  # ny = 33 < 2 * 11 + 12
+    ((34, 35, 28), 8, 11, 30.0, "float32", TOL32, "step_point", {"kernel": "point", "ckpt_interval": 9}),
     # grids the fused 2-D kernel takes WITH the border recursion inside the launch (fused2d_cpml_supported): 70 steps
     # = 68 in 4-step launches + 2 through the slab path, on the same memory variables
     ((192, 256), 8, 40, 40.0, "float32", TOL32, "step2d_fused", {}),            # cfg2's border width, 48-cell images
@@ -77,10 +85,45 @@ def test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw):
     assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (rel(dg, d), rel(ag, a), rel(gg, g))
 
 
+@pytest.mark.parametrize("shape,npml,alpha,kw", [((64, 20, 48), 8, 30.0, {"zchunk": 32}), ((56, 18, 44), 8, 0.0, {"zchunk": 56}),
+                                                 ((70, 17, 40), 12, 25.0, {"zchunk": 35, "ckpt_interval": 20})])
+def test_cpml_z_border_on_the_march(gpu, monkeypatch, shape, npml, alpha, kw):
+    """The z border inside step3d_stream's z march (forward sweeps): correct, but since the line launches exist it
+    costs the step kernel more than the launch it saves (DESIGN.md s.4 CPML), so it is opt-in: FWI_STREAM_ZPML=1."""
+    monkeypatch.setenv("FWI_STREAM_ZPML", "1")
+    test_cpml_vs_oracle(gpu, shape, 8, npml, alpha, "float32", TOL32, "step3d_stream", kw)
+
+
+@pytest.mark.parametrize("kw", [{}, {"update_form": "increment"}, {"dtype": "float64"}])
+def test_cpml_line_launches_equal_the_slab_path(gpu, monkeypatch, kw):
+    """The same shot with the z / y borders as line launches (default) and as the three slab phases per axis
+    (FWI_NO_PML_LINES=1): seismograms, F^T r and gradient agree to round-off."""
+    rng = np.random.default_rng(8)
+    shape, npml, nt = (44, 40, 48), 8, 60
+    c = 1900.0 + 700.0 * rng.random(shape)
+    h, order = 10.0, 8
+    dt = 0.7 * fo.cfl_dt(c.max(), h, 3, order)
+    src = np.array([[2, 20, 24], [22, 3, 24]])
+    rec = np.array([[1, 18, 20], [40, 36, 5], [22, 20, 24]])
+    wav = np.stack([fo.ricker(nt, dt, 0.12 / dt / 8), 0.5 * fo.ricker(nt, dt, 0.12 / dt / 6)], 1)
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("FWI_NO_PML_LINES", env)
+        with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=800.0, abc="cpml", pml_alpha_max=25.0, **kw) as e:
+            d = e.forward(c, (src, wav), rec, save=True)
+            a = e.adjoint(0.7 * d + 0.1 * np.roll(d, 3, axis=0))
+            out.append((d, a, e.gradient()))
+    tol = 1e-12 if kw.get("dtype") == "float64" else 1e-5  # (fp32: the two forms sum the second difference differently)
+    for x, y in zip(*out):
+        assert rel(x, y) < tol
+
+
 @pytest.mark.parametrize("shape,zchunk", [((64, 20, 48), 32), ((56, 18, 44), 56)])
 def test_cpml_z_border_on_the_march_in_the_adjoint_sweep_too(gpu, monkeypatch, shape, zchunk):
     """The adjoint form of the in-kernel z border (two LDS rings) is built and correct but SLOWER than the slab
     launches it replaces (DESIGN.md s.4 CPML), so it is opt-in: FWI_STREAM_ZPML_REV=1.  Same bar as everything else."""
+    monkeypatch.setenv("FWI_STREAM_ZPML", "1")
     monkeypatch.setenv("FWI_STREAM_ZPML_REV", "1")
     test_cpml_vs_oracle(gpu, shape, 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": zchunk})
 
