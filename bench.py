@@ -395,9 +395,13 @@ def main():
         mv = 16 * 3 * (2 * w.npml * w.shape[0] * w.shape[1])  # psi, zeta of three axes, read + written once per step
         r = roofline_entry("cpml3d", w, step_us, BYTES_PER_UPDATE, "hbm",
                            "256^3 forward with the CONVOLUTIONAL PML, npml %d: fields + 50 MB of memory variables = 271 "
-                           "MB do not fit the Infinity Cache (HBM regime: the undamped step kernel alone takes 48 us "
-                           "here); one time step = the step kernel with the x border's recursion in its lanes + 4 slab "
-                           "launches for the z and y borders; `kernel_avg_us` is the whole step" % w.npml,
+                           "MB, and every byte a step touches counts against the Infinity Cache's 256 MiB (streaming "
+                           "hints do not exempt it), so this is an HBM-regime run: algorithmic 369 MB at the ~5.5 TB/s "
+                           "the 512^3 run sustains = 67 us is the floor of a fully fused step.  One time step = the step "
+                           "kernel with the x border's recursion in its lanes + ONE line launch each for the z and the y "
+                           "border (fwi_pml.hip pml_line: they re-read u, C and read-modify-write u' of their border, "
+                           "78 MB each, which is where the distance to that floor is); `kernel_avg_us` is the whole "
+                           "step" % w.npml,
                            extra_bytes=mv)
         r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
         r["us_per_time_step"] = round(step_us, 3)

@@ -64,6 +64,7 @@ struct fwi_ctx {
     bool pair3d = false;
     int pair_zc = 0, pair_tw = 256;
     int fused_skipd = -1;  // Fused2dArgs::skipd (FWI_FUSED2D_SKIPD, read at create)
+    int *fused_order = nullptr;  // Fused2dArgs::tile_order (device; grids of more than one round of tiles with a border)
     int fused_ft = FUSED2D_TILE;  // interior tile edge of the fused 2-D kernel (fused2d_pick_tile; 64 with CPML / increment)
     // convolutional PML: memory variables per axis (z, y, x), compact over that axis' border, and 1-D coefficients
     bool cpml = false;
@@ -780,6 +781,7 @@ struct Impl {
                 a.inc = ctx->inc ? 1 : 0;
                 a.skipd = ctx->fused_skipd;
                 a.ft = ctx->fused_ft;
+                a.tile_order = ctx->fused_order;
                 a.C = (const float *)ctx->C;
                 a.out_cur = (float *)spare[0];
                 a.out_prev = (float *)spare[1];
@@ -1585,6 +1587,14 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && (!ctx->cpml || cpml_in_launch) && !getenv("FWI_NO_FUSED2D") &&
                    (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
     if (ctx->fused2d && !ctx->cpml && !ctx->inc) ctx->fused_ft = fused2d_pick_tile(ctx->gd);
+    if (ctx->fused2d) {
+        std::vector<int> order;
+        fused2d_tile_order(ctx->gd, ctx->fused_ft, cfg->npml, order);
+        if (!order.empty()) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->fused_order, order.size() * sizeof(int)));
+            HIPCHK(ctx, hipMemcpy(ctx->fused_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
     // =1 is the tuning / comparison hook)
     if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {
@@ -1598,12 +1608,12 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
             }
         }
     }
-    ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !ctx->inc && !getenv("FWI_NO_STREAM_XPML") &&
+    ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
     // The z border on the z march is opt-in (FWI_STREAM_ZPML=1) since the line launches exist: it saves the z line
     // launch (~21 us at 256^3 / npml 16) but costs the step kernel more than that (58 -> 84 us: the border planes all
     // fall to the first and last z chunk, whose workgroups then decide the launch): forward 106 against 99 us/step.
-    if (ctx->xpml && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
+    if (ctx->xpml && !ctx->inc && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
         ctx->zpml_fwd = stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, false);
         // the adjoint's form (two rings, 22 planes of LDS per thread column, ~100 registers parked in AGPRs) is slower
         // than the slab launches it replaces (256^3: step kernel 65 -> 125 us against 28 us of slabs): opt-in only
@@ -1658,6 +1668,7 @@ void fwi_destroy(fwi_ctx *ctx) {
                         ctx->pml_zeta_fw[d]})
             if (q) (void)hipFree(q);
     if (ctx->pml_snap) (void)hipFree(ctx->pml_snap);
+    if (ctx->fused_order) (void)hipFree(ctx->fused_order);
     for (fwi_ctx::SpreadSet *sp : {&ctx->src_sp, &ctx->rec_sp})
         for (void *q : {sp->pt_start, sp->owner, sp->weight})
             if (q) (void)hipFree(q);

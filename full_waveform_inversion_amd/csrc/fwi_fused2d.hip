@@ -16,6 +16,8 @@
 // No reference counterpart; arithmetic identical to step2d_tile / the oracle.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -101,7 +103,9 @@ __global__ __launch_bounds__(fused2d_threads(FT)) void step2d_fused(Fused2dArgs 
     // of crossing the fabric once per tile (the fill phase is fabric-bound: 6.5k of the workgroup's 23.6k cycles
     // in the stamped build before, 4.5k after; 3.39 -> 2.69 us/step at 1024^2; tools/stamp_fused2d.py).  FWI_FUSED2D_NOREMAP (tuning hook): a.xcd_remap = 0.
     int tile = blockIdx.x;
-    if (a.xcd_remap) {
+    if (a.tile_order) {  // several rounds of tiles: border tiles first (fused2d_tile_order)
+        tile = a.tile_order[tile];
+    } else if (a.xcd_remap) {
         const int nblk = gridDim.x, x = tile & 7, q = nblk >> 3, r = nblk & 7;  // the first r XCDs hold q + 1 tiles
         tile = x * q + min(x, r) + (tile >> 3);
     }
@@ -361,6 +365,38 @@ extern "C" int fwi_debug_fused2d_stamps(unsigned long long *out, int n) {
 
 int fused2d_num_tiles(const GridDesc &g, int ft) {
     return ((g.nx + ft - 1) / ft) * ((g.nz + ft - 1) / ft);
+}
+
+void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order) {
+    order.clear();
+    static const bool off = getenv("FWI_FUSED2D_NO_TILE_ORDER") != nullptr;  // tuning / A-B hook
+    const int ntx = (g.nx + ft - 1) / ft, ntz = (g.nz + ft - 1) / ft, nt = ntx * ntz;
+    if (off || nt <= 256 || npml <= 0) return;
+    const int HL = (FUSED2D_STEPS * g.r + 3) / 4 * 4, E = ft + 2 * HL;
+    auto heavy = [&](int t, int n) {  // the tile's extended region [t ft - HL, t ft - HL + E) meets a border of the axis
+        const int lo = t * ft - HL;
+        return (lo < npml || lo + E > n - npml) ? 1 : 0;
+    };
+    std::vector<int> first[2], rest;  // corners, edges, interior (row-major)
+    for (int tz = 0; tz < ntz; ++tz)
+        for (int tx = 0; tx < ntx; ++tx) {
+            const int w = heavy(tz, g.nz) + heavy(tx, g.nx);
+            (w == 2 ? first[0] : w == 1 ? first[1] : rest).push_back(tz * ntx + tx);
+        }
+    order.assign(nt, 0);
+    int b = 0;
+    for (auto &v : first)
+        for (int t : v) order[b++] = t;
+    // workgroup b runs on XCD b % 8: the interior tiles in eight contiguous runs, one per XCD
+    const int nh = b;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, start[8], pos[8];
+    for (int i = nh; i < nt; ++i) ++cnt[i & 7];
+    for (int x = 0, acc = 0; x < 8; ++x) {
+        start[x] = acc;
+        pos[x] = 0;
+        acc += cnt[x];
+    }
+    for (int i = nh; i < nt; ++i) order[i] = rest[start[i & 7] + pos[i & 7]++];
 }
 
 int fused2d_pick_tile(const GridDesc &g) {

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
     const int tid = threadIdx.x;
     const int ntx = (g.nx + FT - 1) / FT;
     int tile = blockIdx.x;
-    if (a.xcd_remap) {  // XCD-contiguous tile runs, as in step2d_fused
+    if (a.tile_order) {  // several rounds of tiles: the border tiles (about twice an interior tile's work) go first
+        tile = a.tile_order[tile];
+    } else if (a.xcd_remap) {  // XCD-contiguous tile runs, as in step2d_fused
         const int nblk = gridDim.x, x = tile & 7, q = nblk >> 3, r = nblk & 7;
         tile = x * q + min(x, r) + (tile >> 3);
     }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace fwi {
 
 // Layout halo of every padded field: 4 cells on each side of every stencil
@@ -197,6 +199,8 @@ struct Fused2dArgs {
     int inc;                           // increment form: u_prev / out_prev are the v field in / out
     int skipd;                         // interior tiles skip the damped update: -1 = by tile count, 0 / 1 = forced
     int ft;                            // interior tile edge: 64, 32 or 16 (0 = 64); fused2d_pick_tile()
+    const int *tile_order;             // tile of workgroup b (device array, fused2d_tile_order) or nullptr = the
+                                       // XCD-contiguous row-major order computed in the kernel
     // injection entries, sorted by tile (CSR): every entry whose point lies in the tile's EXTENDED region
     const int *inj_start, *inj_lz, *inj_lx, *inj_col;
     const unsigned char *inj_interior;  // 1 if the point is in the tile's interior (then q gets its share)
@@ -223,6 +227,12 @@ int fused2d_num_tiles(const GridDesc &g, int ft = FUSED2D_TILE);
 // Tile edge that minimises rounds of workgroups x extended tile area (a 512^2 grid makes 64 tiles of 64^2 -- a
 // quarter of the chip -- but 256 of 32^2); FWI_FUSED2D_TILE overrides (tuning / tests).
 int fused2d_pick_tile(const GridDesc &g);
+// Grids of more than one round of tiles: the order in which the workgroups take the tiles.  Tiles whose extended
+// region reaches into the absorbing border do more work per sub-step (the damped update; with the CPML the border
+// recursion, ~2x an interior tile): they go FIRST, dealt evenly over the XCDs, corners before edges, so that the launch
+// does not end on them; the interior tiles follow in XCD-contiguous row-major runs as before.  Empty result = one round
+// or less (the kernel's own numbering is kept).
+void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order);
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
 // True when the fused kernel can carry the CPML of this grid: every border cell a tile sees lies deep inside that
 // tile's extended region or against the outside of the grid (conditions at fused2d_cpml_supported).

@@ -1098,6 +1098,26 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
     if (no_remap) zchunk = -zchunk;
     if constexpr (std::is_same<T, float>::value) {
         if (a.v) {  // increment form (fp32 only; the adjoint sweep images one pairing per step)
+            if constexpr (R == 4 && !DAMP) {
+                if (a.xp_mode == 1) {  // ... with the x border's recursion in the lanes (the term joins q, hence v' and u')
+                    if (a.q_out)
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true, false, 1>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    else
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 1>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    return hipGetLastError();
+                }
+                if (a.xp_mode == 2) {
+                    if (a.q_in)
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true, false, 2>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    else
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 2>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    return hipGetLastError();
+                }
+            }
             if (a.q_out)
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true>), grid, block, 0, s, a, g,
                                    zchunk, nxt, nyt, nblk, tw);

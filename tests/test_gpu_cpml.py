@@ -36,6 +36,7 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((20, 18, 300), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {}),           # two x tiles of 152 / 148 columns
     ((24, 16, 256), 8, 16, 20.0, "float32", TOL32, "step3d_stream", {}),          # full 256-column tiles (FULL path)
     ((30, 24, 40), 8, 12, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 7}), # several z chunks per tile
+    ((40, 36, 64), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"update_form": "increment"}),  # ... in increment form
     # grids on which the z border can ride on the z march as well (stream_zpml_supported; opt-in, see
     # test_cpml_z_border_on_the_march) -- by default their z and y borders run as line launches
     ((64, 20, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": 32}),   # a seam between the two borders
@@ -55,6 +56,8 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((150, 216), 8, 6, 0.0, "float32", TOL32, "step2d_fused", {}),              # high borders off the 16-byte groups,
                                                                                 # last tiles exactly npml + 16 wide
     ((192, 256), 8, 24, 40.0, "float32", TOL32, "step2d_fused", {"ckpt_interval": 16}),
+    ((1130, 1070), 8, 20, 30.0, "float32", TOL32, "step2d_fused", {}),          # 306 tiles: more than one round of
+                                                                                # workgroups, border tiles first
     ((149, 216), 8, 6, 0.0, "float32", TOL32, "step2d_tile", {}),               # last tile one cell too narrow: slab path
 ]
 

@@ -1050,6 +1050,11 @@ def fuzz_option_combinations(seed, ncases, setenv, maxdim=37):
             pn.forward(src, w, rec)
             pn.adjoint(r)
             gn = pn.gradient()
-            gtol = 2e-4 + 0.5 * np.linalg.norm(g - gn) / max(np.linalg.norm(gn), 1e-300)
+            quant = np.linalg.norm(g - gn) / max(np.linalg.norm(gn), 1e-300)
+            gtol = 2e-4 + 0.5 * quant
+            # ... but it must be the bf16 store that it reproduces: where the quantisation effect stands clear of the
+            # fp32 error level, the engine's gradient lies nearer the bf16 oracle than the native one
+            if quant > 2e-3:
+                assert np.linalg.norm(gg - g) < np.linalg.norm(gg - gn), tag
         for x, ref, tol in ((d0, d, 2e-5), (dg, d, 2e-5), (ag, a, 2e-5), (gg, g, gtol)):
             assert np.linalg.norm(x - ref) < tol * np.linalg.norm(ref) + FLOOR, tag

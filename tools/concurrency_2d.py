@@ -13,13 +13,16 @@ from full_waveform_inversion_amd import Engine, workloads  # noqa: E402
 
 
 def main():
-    w = workloads.cfg2(1.0)
+    # usage: concurrency_2d.py [scale of configs[1], default 1.0 = 1024^2; 0.5 = 512^2, 0.25 = 256^2] [max engines]
+    scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    emax = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    w = workloads.cfg2(scale)
     w.nt = 1000
     wav = w.wavelet()
     c = w.c.astype(np.float32)
-    for ty in (8, 16):
+    for ty in (8,):  # (rows per workgroup of the single-step kernel; the fused kernel ignores it)
         os.environ["FWI_STREAM_TY"] = str(ty)
-        for E in (1, 2, 3, 4):
+        for E in [e for e in (1, 2, 3, 4, 6) if e <= emax]:
             engines = [Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml) for _ in range(E)]
             for e in engines:
                 e.set_model(c)

@@ -40,7 +40,7 @@ def main():
         if not stats:
             continue
         shutil.copy(stats, os.path.join(DST, "r03_kernel_stats_%s.csv" % leg))
-        rows = [r for r in csv.DictReader(open(stats)) if "fwi::step" in r["Name"] or "fwi::pml_kernel" in r["Name"]]
+        rows = [r for r in csv.DictReader(open(stats)) if "fwi::step" in r["Name"] or "fwi::pml_kernel" in r["Name"] or "fwi::pml_line" in r["Name"]]
         per_kernel = {}
         for r in rows:
             ent = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct_of_gpu_time": float(r["Percentage"])}
@@ -60,7 +60,7 @@ def main():
             steps = max(e["calls"] for k, e in per_kernel.items() if k.startswith("step"))
             dom = {"calls": steps, "avg_ns": sum(e["calls"] * e["avg_ns"] for e in per_kernel.values()) / steps,
                    "traffic_bytes_per_launch": sum(e["calls"] * e["traffic_bytes_per_launch"] for e in per_kernel.values()) / steps,
-                   "note": "per TIME STEP: all kernels of the leg (step kernel + slab launches) / step-kernel calls"}
+                   "note": "per TIME STEP: all kernels of the leg (step kernel + line / slab launches) / step-kernel calls"}
         elif len(per_kernel) > 1 and all("traffic_bytes_per_launch" in e for e in per_kernel.values()):
             # several step kernels share the leg (gradient: store / plain / paired-imaging launches): call-weighted mean
             n = sum(e["calls"] for e in per_kernel.values())
