@@ -188,6 +188,10 @@ __global__ __launch_bounds__(fused2d_threads(FT)) void step2d_fused(Fused2dArgs 
         float *const qslot = a.q_base + (int64_t)(a.istride <= 1 ? n : n / a.istride) * g.npts;
         // the region that must still be exact after this sub-step (compile-time: the loop is unrolled)
         constexpr int lo = (s + 1) * R, hi = E - (s + 1) * R;
+        // (whole rows in x: restricting the sub-step to the 22 / 20 / 18 / 16 groups per row that hold active columns
+        // makes 2 + 2 + 2 + 1 trips of the 1024 threads out of 3 + 2 + 2 + 2, but rows that are not whole 16-lane passes
+        // of a ds_read_b128 conflict -- 1024^2 2.72 -> 2.96 us/step -- and narrowing the last sub-step alone, whose 16
+        // groups are exactly one pass, changed nothing (2.79): the sub-steps are not bound by their trip count)
         constexpr int c_lo = 0, w4 = E4, nact = (hi - lo) * w4;
         constexpr int TRIPS = (nact + FNT - 1) / FNT;  // groups per thread in this sub-step
         // imaging: start fetching this step's q for the interior groups now, use it after the update

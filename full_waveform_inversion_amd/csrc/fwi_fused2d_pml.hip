@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         const bool qstep = (SAVE_Q || IMAGE) && (a.istride <= 1 || n % a.istride == 0);
         float *const qslot = a.q_base + (int64_t)(a.istride <= 1 ? n : n / a.istride) * g.npts;
         constexpr int lo = (s + 1) * R, hi = E - (s + 1) * R;
-        constexpr int w4 = E4, nact = (hi - lo) * w4;
+        constexpr int c_lo = lo / 4, w4 = (hi + 3) / 4 - c_lo, nact = (hi - lo) * w4;  // (active columns only, as in step2d_fused)
         constexpr int TRIPS = (nact + FNT - 1) / FNT;
         nt4 qv[IPT];
         if (IMAGE) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         for (int i = 0; i < TRIPS; ++i) {
             const int gi = tid + i * FNT;
             if (gi >= nact) break;
-            const int lz = lo + gi / w4, l4 = gi % w4;
+            const int lz = lo + gi / w4, l4 = c_lo + gi % w4;
             // C of this group from global memory (zero halo outside the grid), in flight under the LDS reads below
             const int zc = min(max(z0 + lz, -1), g.nz), xc = min(max(x0 + 4 * l4, -4), xpad);
             const q4 Cc = (FWI_CPML_ABLATE & 4) ? q4{{.1f, .1f, .1f, .1f}}
