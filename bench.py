@@ -232,9 +232,16 @@ def main():
     def exchange(e):
         # a communicator that neither comes up nor fails must not hang the job: hard exit with a traceback
         faulthandler.dump_traceback_later(float(os.environ.get("FWI_COMM_INIT_TIMEOUT", "300")), exit=True)
+        # RCCL prints a version banner on STDOUT at communicator init (RCCL 2.27: "RCCL version : ...", five lines):
+        # this process' stdout carries ONE json line, so the library writes to stderr while it comes up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
         try:
             return RcclExchange(e, rdzv)
         finally:
+            os.dup2(saved, 1)
+            os.close(saved)
             faulthandler.cancel_dump_traceback_later()
 
     def max_over_ranks(e, el):

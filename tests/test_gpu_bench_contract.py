@@ -65,6 +65,8 @@ def test_the_multi_rank_path_as_the_driver_launches_it_with_one_rank(gpu):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
+    # ... and nothing else on stdout: RCCL's version banner at communicator init is sent to stderr (bench.py, exchange)
+    assert [ln for ln in p.stdout.decode().splitlines() if ln.strip()] == lines, p.stdout.decode()[:600]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and "rccl allreduce" in d["config"]["exchange"]
     assert d["value"] > 0
