@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--npml", type=int, default=-1, help="override the workload's border width")
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--zchunk", type=int, default=0, help="planes per workgroup of the 3-D stream kernel (0 = tuned)")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"])
     ap.add_argument("--update-form", default="standard", choices=["standard", "increment"])
@@ -31,7 +32,7 @@ def main():
     wav = w.wavelet(np.dtype(a.dtype).type)
     src = w.src_idx[:1]
     e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, kernel=a.kernel, dtype=a.dtype, abc=a.abc,
-               update_form=a.update_form, store_dtype=a.store_dtype,
+               update_form=a.update_form, store_dtype=a.store_dtype, zchunk=a.zchunk,
                pml_alpha_max=(3.14159 * w.f0 if a.abc == "cpml" else 0.0))
     e.set_model(w.c.astype(a.dtype))
     npts = int(np.prod(w.shape))
