@@ -568,17 +568,28 @@ struct Impl {
             const int ntx = (g.nx + FT - 1) / FT, ntz = (g.nz + FT - 1) / FT, ntile = ntx * ntz;
             struct Ent { int tile, lz, lx, col; unsigned char interior; };
             std::vector<Ent> ents;
+            // (with the CPML inside the launch the tiles are whole, with one overlap seam per axis: fused2d_origin /
+            // fused2d_own give every tile's first cell and the first cell it owns)
+            const int seam = ctx->cpml ? 1 : 0;
+            struct Ax { int t, l; bool own; };
+            auto tiles_of = [&](int c, int nn, int nt, Ax *out) {  // tiles whose extended region holds coordinate c
+                int m = 0;
+                // HL <= FT and the seam shifts a tile by less than FT: the owning tile's index is within 2 of c / FT
+                for (int t = std::max(0, c / FT - 1); t <= std::min(nt - 1, c / FT + 2); ++t) {
+                    const int o = fused2d_origin(t, nn, FT, seam);
+                    if (c < o - HL || c >= o + FT + HL) continue;
+                    const int lo = fused2d_own(t, nn, FT, seam), hi = t + 1 < nt ? fused2d_own(t + 1, nn, FT, seam) : nn;
+                    out[m++] = Ax{t, c - (o - HL), c >= lo && c < hi};
+                }
+                return m;
+            };
             for (int i = 0; i < n; ++i) {
                 const int z = idx[(size_t)i * g.ndim], x = idx[(size_t)i * g.ndim + 1];
-                // HL <= FT: only the owning tile and its direct neighbours can hold the point
-                for (int tz = std::max(0, z / FT - 1); tz <= std::min(ntz - 1, z / FT + 1); ++tz) {
-                    if (z < tz * FT - HL || z >= tz * FT + FT + HL) continue;
-                    for (int tx = std::max(0, x / FT - 1); tx <= std::min(ntx - 1, x / FT + 1); ++tx) {
-                        if (x < tx * FT - HL || x >= tx * FT + FT + HL) continue;
-                        const bool in = z / FT == tz && x / FT == tx;
-                        ents.push_back({tz * ntx + tx, z - (tz * FT - HL), x - (tx * FT - HL), i, (unsigned char)in});
-                    }
-                }
+                Ax az[4], ax[4];
+                const int mz = tiles_of(z, g.nz, ntz, az), mx = tiles_of(x, g.nx, ntx, ax);
+                for (int p = 0; p < mz; ++p)
+                    for (int q = 0; q < mx; ++q)
+                        ents.push_back({az[p].t * ntx + ax[q].t, az[p].l, ax[q].l, i, (unsigned char)(az[p].own && ax[q].own)});
             }
             std::stable_sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) {
                 if (x.tile != y.tile) return x.tile < y.tile;
@@ -1589,7 +1600,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (ctx->fused2d && !ctx->cpml && !ctx->inc) ctx->fused_ft = fused2d_pick_tile(ctx->gd);
     if (ctx->fused2d) {
         std::vector<int> order;
-        fused2d_tile_order(ctx->gd, ctx->fused_ft, cfg->npml, order);
+        fused2d_tile_order(ctx->gd, ctx->fused_ft, cfg->npml, order, ctx->cpml ? 1 : 0);
         if (!order.empty()) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->fused_order, order.size() * sizeof(int)));
             HIPCHK(ctx, hipMemcpy(ctx->fused_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -371,14 +371,14 @@ int fused2d_num_tiles(const GridDesc &g, int ft) {
     return ((g.nx + ft - 1) / ft) * ((g.nz + ft - 1) / ft);
 }
 
-void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order) {
+void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order, int seam) {
     order.clear();
     static const bool off = getenv("FWI_FUSED2D_NO_TILE_ORDER") != nullptr;  // tuning / A-B hook
     const int ntx = (g.nx + ft - 1) / ft, ntz = (g.nz + ft - 1) / ft, nt = ntx * ntz;
     if (off || nt <= 256 || npml <= 0) return;
     const int HL = (FUSED2D_STEPS * g.r + 3) / 4 * 4, E = ft + 2 * HL;
     auto heavy = [&](int t, int n) {  // the tile's extended region [t ft - HL, t ft - HL + E) meets a border of the axis
-        const int lo = t * ft - HL;
+        const int lo = fused2d_origin(t, n, ft, seam) - HL;
         return (lo < npml || lo + E > n - npml) ? 1 : 0;
     };
     std::vector<int> first[2], rest;  // corners, edges, interior (row-major)

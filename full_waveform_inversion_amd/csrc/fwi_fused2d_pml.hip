@@ -14,9 +14,12 @@
 // tiling budgets r cells of validity loss per sub-step, which is still enough here because of WHERE the border
 // cells are: fused2d_cpml_supported() admits a grid only if every border cell a tile holds in its extended region
 // lies in that tile's interior -- at least HL cells from every INWARD edge of the region, where the extra r cells
-// are always valid -- with nothing but the outside of the grid (exact zeros) on its other side.  Grids that do not
-// qualify (border wider than FT - HL, a last tile narrower than npml + HL, a single tile per axis) keep the slab
-// path.  The adjoint sweep runs the transposed recursion: zt' = b zt + mu; pt' = b pt - D mu - D (a zt');
+// are always valid -- with nothing but the outside of the grid (exact zeros) on its other side.  So that a narrow last
+// tile does not disqualify a grid (it did for 5 of 6 grid sizes at npml 40), the tiles of this kernel are WHOLE with one
+// overlap seam in the middle of each axis (fused2d_origin: the upper half of the tiles is anchored at the high end; the
+// two tiles at the seam both compute the overlap, the lower one stores it, the host's injection / sampling tables
+// follow the same ownership).  Grids that still do not qualify (border wider than FT - HL = 48, a single tile per axis,
+// two tiles that both see both borders) keep the slab path.  The adjoint sweep runs the transposed recursion: zt' = b zt + mu; pt' = b pt - D mu - D (a zt');
 // term = E (a zt') - D (a pt'), two dependent neighbour reads, hence two barriers before the update.
 //
 // C is read from global memory per group here (L2-resident; the third LDS image of step2d_fused is what the four
@@ -46,11 +49,19 @@ constexpr int cpml_halo(int r) { return (FUSED2D_STEPS * r + 3) / 4 * 4; }
 bool fused2d_cpml_supported(const GridDesc &g, int npml) {
     if (g.ndim != 2 || g.r != 4 || npml < 1) return false;  // (O(8) is what is instantiated)
     const int HL = cpml_halo(g.r), FT = FUSED2D_TILE;
-    if (npml > FT - HL) return false;  // the low border must end before the second tile's halo begins
+    if (npml > FT - HL) return false;  // the memory-variable images hold 48 border cells
+    // Every tile (whole tiles, one overlap seam per axis: fused2d_origin) must see each border either not at all or
+    // from a side where nothing but the outside of the grid lies beyond it, and never both borders of an axis
     for (int n : {g.nz, g.nx}) {
-        if (n <= FT) return false;                  // one tile would hold both borders of the axis
-        const int B = (n - 1) / FT * FT;            // first cell of the last tile
-        if (n - B < npml + HL) return false;        // the high border must start HL cells into the last tile
+        if (n <= FT) return false;
+        const int nt = (n + FT - 1) / FT;
+        for (int t = 0; t < nt; ++t) {
+            const int lo = fused2d_origin(t, n, FT, 1) - HL, hi = lo + FT + 2 * HL;
+            const bool low = lo < npml, high = hi > n - npml;  // border cells in the extended region
+            if (low && high) return false;
+            if (low && lo > 0) return false;     // the low border would begin inside this tile's halo
+            if (high && hi < n) return false;    // ... the high border end in it
+        }
     }
     return true;
 }
@@ -89,7 +100,9 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         tile = x * q + min(x, r) + (tile >> 3);
     }
     const int tz = tile / ntx, tx = tile % ntx;
-    const int z0 = tz * FT - HL, x0 = tx * FT - HL;  // grid coordinates of extended (0, 0)
+    // whole tiles with one overlap seam per axis (fused2d_origin); a tile stores from its first OWNED cell on
+    const int z0 = fused2d_origin(tz, g.nz, FT, 1) - HL, x0 = fused2d_origin(tx, g.nx, FT, 1) - HL;  // extended (0, 0)
+    const int own_lz = fused2d_own(tz, g.nz, FT, 1) - z0, own_l4 = (fused2d_own(tx, g.nx, FT, 1) - x0) >> 2;  // (>= HL, HL / 4)
     const int npml = a.pml_npml;
     const int xpad = (g.nx + 3) & ~3;
 
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
             prv[lz][l4] = un;
             if (SAVE_Q && qstep) {
                 const int z = z0 + lz, x = x0 + 4 * l4;
-                const bool interior = lz >= HL && lz < HL + FT && l4 >= HL / 4 && l4 < (HL + FT) / 4;
+                const bool interior = lz >= own_lz && lz < HL + FT && l4 >= own_l4 && l4 < (HL + FT) / 4;
                 if (interior && z < g.nz && x < g.nx) {
                     nt4 v = {q.v[0], q.v[1], q.v[2], q.v[3]};
                     __builtin_nontemporal_store(v, reinterpret_cast<nt4 *>(qslot + (int64_t)z * g.cx + x));
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         if (ii >= NI) break;
         const int lz = HL + ii / (FT / 4), l4 = HL / 4 + ii % (FT / 4);
         const int z = z0 + lz, x = x0 + 4 * l4;
-        if (z >= g.nz || x >= g.nx) continue;
+        if (z >= g.nz || x >= g.nx || lz < own_lz || l4 < own_l4) continue;  // (below the seam's overlap: the other tile's)
         const int64_t p = g.off0 + (int64_t)z * g.sz + x;
         *reinterpret_cast<q4 *>(a.out_cur + p) = cur[lz][l4];
         *reinterpret_cast<q4 *>(a.out_prev + p) = prv[lz][l4];
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         for (int i = tid; i < npml * (FT / 4); i += FNT) {
             const int r = i / (FT / 4), l4 = HL / 4 + i % (FT / 4);
             const int z = z0 + pbz + r, x = x0 + 4 * l4;
-            if (x >= g.nx) continue;
+            if (x >= g.nx || l4 < own_l4) continue;
             const int j = z < npml ? z : z - (g.nz - 2 * npml);
             const int64_t o = (int64_t)j * g.cx + x;
             *reinterpret_cast<q4 *>(a.pml_psi[0] + o) = pz[r][l4];
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
         for (int i = tid; i < FT * NXG; i += FNT) {
             const int lz = HL + i / NXG, gx = i % NXG;
             const int z = z0 + lz;
-            if (z >= g.nz) continue;
+            if (z >= g.nz || lz < own_lz) continue;
             const q4 p = px[lz][gx], q = zx[lz][gx];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

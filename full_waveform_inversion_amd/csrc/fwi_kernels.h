@@ -223,6 +223,19 @@ struct Fused2dArgs {
     float pml_dk[5], pml_dk1[5];
 };
 
+// Tiling of an axis of n cells by WHOLE tiles of ft cells with one overlap seam in the middle -- the fused 2-D kernel
+// with the CPML inside, whose border tiles must be whole (the recursion reaches 2 r cells per sub-step, so a border cell
+// may not sit in a tile's halo): the lower half of the tiles starts at t * ft, the upper half is anchored at the high
+// end (origins rounded up to a 16-byte group; the last tile may overhang n by <= 3 cells like any partial tile), and the
+// two tiles either side of the seam overlap by nt * ft - n cells in the interior of the grid, which both compute and
+// the lower one stores.  `seam` = 0: the plain tiling t * ft.  fused2d_own: the first cell of tile t that t owns.
+__host__ __device__ inline int fused2d_origin(int t, int n, int ft, int seam) {
+    const int nt = (n + ft - 1) / ft;
+    return (!seam || nt < 2 || t < nt / 2) ? t * ft : ((n - (nt - t) * ft + 3) & ~3);
+}
+__host__ __device__ inline int fused2d_own(int t, int n, int ft, int seam) {
+    return t == 0 ? 0 : fused2d_origin(t - 1, n, ft, seam) + ft;  // (= the tile's origin except just above the seam)
+}
 int fused2d_num_tiles(const GridDesc &g, int ft = FUSED2D_TILE);
 // Tile edge that minimises rounds of workgroups x extended tile area (a 512^2 grid makes 64 tiles of 64^2 -- a
 // quarter of the chip -- but 256 of 32^2); FWI_FUSED2D_TILE overrides (tuning / tests).
@@ -232,7 +245,7 @@ int fused2d_pick_tile(const GridDesc &g);
 // recursion, ~2x an interior tile): they go FIRST, dealt evenly over the XCDs, corners before edges, so that the launch
 // does not end on them; the interior tiles follow in XCD-contiguous row-major runs as before.  Empty result = one round
 // or less (the kernel's own numbering is kept).
-void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order);
+void fused2d_tile_order(const GridDesc &g, int ft, int npml, std::vector<int> &order, int seam = 0);
 hipError_t launch_fused2d(const GridDesc &g, const Fused2dArgs &a, hipStream_t s);
 // True when the fused kernel can carry the CPML of this grid: every border cell a tile sees lies deep inside that
 // tile's extended region or against the outside of the grid (conditions at fused2d_cpml_supported).

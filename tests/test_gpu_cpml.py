@@ -58,7 +58,13 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((192, 256), 8, 24, 40.0, "float32", TOL32, "step2d_fused", {"ckpt_interval": 16}),
     ((1130, 1070), 8, 20, 30.0, "float32", TOL32, "step2d_fused", {}),          # 306 tiles: more than one round of
                                                                                 # workgroups, border tiles first
-    ((149, 216), 8, 6, 0.0, "float32", TOL32, "step2d_tile", {}),               # last tile one cell too narrow: slab path
+    # whole tiles with an overlap seam in the middle of each axis (fused2d_origin): a last tile narrower than npml + 16
+    # no longer sends the grid to the slab path
+    ((149, 216), 8, 6, 0.0, "float32", TOL32, "step2d_fused", {}),              # seams of 43 and 40 cells
+    ((200, 300), 8, 40, 35.0, "float32", TOL32, "step2d_fused", {}),            # ... with cfg2's border width
+    ((333, 131), 8, 24, 20.0, "float32", TOL32, "step2d_fused", {"ckpt_interval": 12}),  # odd sizes: origins rounded to 4
+    ((130, 250), 8, 16, 30.0, "float32", TOL32, "step2d_fused", {}),            # two tiles along z: both hold a border
+    ((60, 216), 8, 6, 0.0, "float32", TOL32, "step2d_tile", {}),                # one tile along z: slab path
 ]
 
 
