@@ -76,6 +76,9 @@ struct fwi_ctx {
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
     void *pml_psi_fw[3] = {nullptr, nullptr, nullptr}, *pml_zeta_fw[3] = {nullptr, nullptr, nullptr};
+    // 2-D contexts that carry the CPML inside the fused launch: the set of arrays the launch writes (swapped with the
+    // set it read after every launch; zeroed once -- the pad columns of the z border's rows are never written)
+    void *pml_spare_psi[3] = {nullptr, nullptr, nullptr}, *pml_spare_zeta[3] = {nullptr, nullptr, nullptr};
     void *pml_snap = nullptr;
     size_t pml_snap_stride = 0;  // bytes of one snapshot of the memory variables
     void *pml_a[3] = {nullptr, nullptr, nullptr}, *pml_b[3] = {nullptr, nullptr, nullptr};
@@ -835,6 +838,8 @@ struct Impl {
                     for (int d = 0; d < 2; ++d) {  // z -> 0, x -> 1
                         a.pml_psi[d] = (float *)p.psi[d ? 2 : 0];
                         a.pml_zeta[d] = (float *)p.zeta[d ? 2 : 0];
+                        a.pml_psi_out[d] = (float *)ctx->pml_spare_psi[d ? 2 : 0];
+                        a.pml_zeta_out[d] = (float *)ctx->pml_spare_zeta[d ? 2 : 0];
                         a.pml_a[d] = (const float *)p.a[d ? 2 : 0];
                         a.pml_b[d] = (const float *)p.b[d ? 2 : 0];
                     }
@@ -843,6 +848,10 @@ struct Impl {
                         a.pml_dk1[k] = (float)p.dk1[k];
                     }
                     HIPCHK(ctx, launch_fused2d_cpml(g, a, ctx->stream));
+                    for (int d : {0, 2}) {  // the written set becomes the current one of this sweep
+                        std::swap(sw.pml_fw ? ctx->pml_psi_fw[d] : ctx->pml_psi[d], ctx->pml_spare_psi[d]);
+                        std::swap(sw.pml_fw ? ctx->pml_zeta_fw[d] : ctx->pml_zeta[d], ctx->pml_spare_zeta[d]);
+                    }
                 } else {
                     HIPCHK(ctx, launch_fused2d(g, a, ctx->stream));
                 }
@@ -1443,6 +1452,12 @@ int create_impl(fwi_ctx *ctx) {
             ctx->pml_bytes[d] = cnt * es;
             HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d]));
             HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d]));
+            if (ctx->fused2d) {  // the set the fused launch writes (see fwi_ctx::pml_spare_psi)
+                HIPCHK(ctx, hipMalloc(&ctx->pml_spare_psi[d], ctx->pml_bytes[d]));
+                HIPCHK(ctx, hipMalloc(&ctx->pml_spare_zeta[d], ctx->pml_bytes[d]));
+                HIPCHK(ctx, hipMemsetAsync(ctx->pml_spare_psi[d], 0, ctx->pml_bytes[d], ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->pml_spare_zeta[d], 0, ctx->pml_bytes[d], ctx->stream));
+            }
             HIPCHK(ctx, hipMalloc(&ctx->pml_a[d], (size_t)n * es));
             HIPCHK(ctx, hipMalloc(&ctx->pml_b[d], (size_t)n * es));
             std::vector<double> pa(n), pb(n);  // cpml_profiles() of the oracle
@@ -1676,7 +1691,7 @@ void fwi_destroy(fwi_ctx *ctx) {
         if (v) (void)hipFree(v);
     for (int d = 0; d < 3; ++d)
         for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d], ctx->pml_psi_fw[d],
-                        ctx->pml_zeta_fw[d]})
+                        ctx->pml_zeta_fw[d], ctx->pml_spare_psi[d], ctx->pml_spare_zeta[d]})
             if (q) (void)hipFree(q);
     if (ctx->pml_snap) (void)hipFree(ctx->pml_snap);
     if (ctx->fused_order) (void)hipFree(ctx->fused_order);

@@ -548,15 +548,16 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
             *reinterpret_cast<q4 *>(gp) = gv;
         }
     }
-    if (pbz >= 0) {  // (every border row this tile holds is one of its interior rows)
+    if (pbz >= 0) {  // (a border row this tile holds is one of its interior rows -- its own, or, in the tile just above
+                     // the seam of a three-tile axis, one the tile below owns and stores)
         for (int i = tid; i < npml * (FT / 4); i += FNT) {
             const int r = i / (FT / 4), l4 = HL / 4 + i % (FT / 4);
             const int z = z0 + pbz + r, x = x0 + 4 * l4;
-            if (x >= g.nx || l4 < own_l4) continue;
+            if (x >= g.nx || l4 < own_l4 || pbz + r < own_lz || pbz + r >= HL + FT) continue;
             const int j = z < npml ? z : z - (g.nz - 2 * npml);
             const int64_t o = (int64_t)j * g.cx + x;
-            *reinterpret_cast<q4 *>(a.pml_psi[0] + o) = pz[r][l4];
-            *reinterpret_cast<q4 *>(a.pml_zeta[0] + o) = zz[r][l4];
+            *reinterpret_cast<q4 *>(a.pml_psi_out[0] + o) = pz[r][l4];
+            *reinterpret_cast<q4 *>(a.pml_zeta_out[0] + o) = zz[r][l4];
         }
     }
     if (pbx >= 0) {
@@ -567,12 +568,12 @@ __global__ __launch_bounds__(1024) void step2d_fused_cpml(Fused2dArgs a, GridDes
             const q4 p = px[lz][gx], q = zx[lz][gx];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int x = x0 + pbx + 4 * gx + c;
-                if (x >= 0 && x < g.nx && (x < npml || x >= g.nx - npml)) {
+                const int x = x0 + pbx + 4 * gx + c, lx = pbx + 4 * gx + c;
+                if (x >= 0 && x < g.nx && (x < npml || x >= g.nx - npml) && lx >= 4 * own_l4 && lx < HL + FT) {
                     const int j = x < npml ? x : x - (g.nx - 2 * npml);
                     const int64_t o = (int64_t)z * (2 * npml) + j;
-                    a.pml_psi[1][o] = p.v[c];
-                    a.pml_zeta[1][o] = q.v[c];
+                    a.pml_psi_out[1][o] = p.v[c];
+                    a.pml_zeta_out[1][o] = q.v[c];
                 }
             }
         }

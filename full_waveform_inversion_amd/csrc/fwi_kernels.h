@@ -219,6 +219,10 @@ struct Fused2dArgs {
     // weights (dk: of a memory variable, dk1: of the field, see PmlArgs) and the direction of the recursion
     int pml_npml, pml_rev;
     float *pml_psi[2], *pml_zeta[2];
+    // where the launch WRITES the advanced memory variables of the cells its tiles own (a second set of arrays, swapped
+    // with the first by the host after the launch): a tile also reads border cells of its halo, which a neighbouring
+    // tile owns and, in a launch of several rounds of workgroups, may already have advanced
+    float *pml_psi_out[2], *pml_zeta_out[2];
     const float *pml_a[2], *pml_b[2];
     float pml_dk[5], pml_dk1[5];
 };

@@ -412,8 +412,15 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
 #ifndef PML_LINE_BS1
 #define PML_LINE_BS1 8
 #endif
-template <typename T, int R, int D, bool REV, bool NT, int VL>
+// Diagnostic builds only (-DPML_LINE_ABLATE=bits; results are wrong): 1 = no arithmetic (old values stored back), 2 = no
+// read-modify-write of u' / v' / q, 4 = no memory-variable stores, 8 = no field loads (u window stays zero), 16 = no
+// memory-variable loads
+#ifndef PML_LINE_ABLATE
+#define PML_LINE_ABLATE 0
+#endif
+template <typename T, int R, int D, bool REV, int VL, bool HV, bool HQ>
 __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
+    constexpr bool NT = true;  // (streaming hints on the memory variables: read once, written once per step)
     // cells per block = the loads a thread keeps in flight (5-7 per cell): 4-byte lanes take twice the cells to have
     // the same bytes per wave on the way while a block is computed, and half the round trips per line
     constexpr int BS = VL == 1 ? PML_LINE_BS1 : 4;
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     typedef T ntv_t __attribute__((ext_vector_type(VL > 1 ? VL : 2)));
     static_assert(D == 0 || D == 1, "z or y axis");
     __shared__ T ca[MAXC], cb[MAXC];
+    __shared__ int cin[MAXC];  // 1 = a border row this segment owns (and stores)
 
     const int n = D == 0 ? g.nz : g.ny, npml = p.npml;
     // (the low segment computes memory variables up to 2r rows past its end -- all zero off the border, but not if the
@@ -442,6 +450,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
         const bool in = j >= 0 && j < n && (merged ? (j < npml || j >= n - npml) : seg == 0 ? j < npml : j >= n - npml);
         ca[i] = in ? p.a[D][j] : T(0);
         cb[i] = in ? p.b[D][j] : T(0);
+        cin[i] = in ? 1 : 0;
     }
     __syncthreads();
 
@@ -496,10 +505,6 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
             stn<T, VL>(q, v);
         }
     };
-    auto inb = [&](int j) {  // border rows this segment owns (and stores)
-        return j >= 0 && j < n && (merged ? (j < npml || j >= n - npml) : seg == 0 ? j < npml : j >= n - npml);
-    };
-
     struct In {
         V un[BS];  // new field rows of the window
         V o0[BS];  // old values of the variable advanced first, at its new rows
@@ -512,16 +517,20 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
         const bool out = i0 >= ib;
 #pragma unroll
         for (int t = 0; t < BS; ++t) {
-            in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
-            in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
-            in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
+            if (!(PML_LINE_ABLATE & 8)) in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
+            if (!(PML_LINE_ABLATE & 16)) {
+                in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
+                in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
+            }
             const int jr = out ? min(i0 + t, ie - 1) : ib;  // (warm-up blocks re-read one row: cache hits)
-            in.c[t] = ldf(p.C, jr);
-            in.up[t] = ldf(p.u_next, jr);
+            if (!(PML_LINE_ABLATE & 2)) {
+                in.c[t] = ldf(p.C, jr);
+                in.up[t] = ldf(p.u_next, jr);
+            }
             // (vv / qq stay unset when the option is off: giving them values costs 64 live registers and a quarter of
             // the launch's speed -- 256^3 / npml 16 forward 100 -> 126 us/step, measured)
-            if (p.v) in.vv[t] = ldf(p.v, jr);
-            if (p.q_out) in.qq[t] = ldn<T, VL>(p.q_out + qbase + (int64_t)min(max(jr, 0), n - 1) * qst);
+            if constexpr (HV && !(PML_LINE_ABLATE & 2)) in.vv[t] = ldf(p.v, jr);
+            if constexpr (HQ && !(PML_LINE_ABLATE & 2)) in.qq[t] = ldn<T, VL>(p.q_out + qbase + (int64_t)min(max(jr, 0), n - 1) * qst);
         }
     };
 
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     v.v[q] = fma(bv, cur.o0[t].v[q], av * du);
                 }
                 Pw[2 * R + t] = v;
-                if (act && inb(j)) stm(m0, j, v);
+                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + R + t]) stm(m0, j, v);
             }
             // zeta'(i) = b zeta + a (E u + D psi');  term = D psi' + zeta'   (warm-up blocks: nothing to form)
             if (out)
@@ -588,19 +597,19 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     add.v[q] = cur.c[t].v[q] * (dp + zn.v[q]);
                 }
                 const bool row = act && out && i < ie;
-                if (row && inb(i)) stm(m1, i, zn);
-                if (row) {
+                if (!(PML_LINE_ABLATE & 4) && row && cin[tb + t]) stm(m1, i, zn);
+                if (!(PML_LINE_ABLATE & 2) && row) {
                     V un = cur.up[t];
 #pragma unroll
                     for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
                     stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
-                    if (p.v) {
+                    if constexpr (HV) {
                         V w = cur.vv[t];
 #pragma unroll
                         for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
                         stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
                     }
-                    if (p.q_out) {
+                    if constexpr (HQ) {
                         V w = cur.qq[t];
 #pragma unroll
                         for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     zt.v[q] = fma(bv, cur.o0[t].v[q], cur.un[t].v[q]);
                     Uw[3 * R + t].v[q] = av * zt.v[q];
                 }
-                if (act && inb(j)) stm(m0, j, zt);
+                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + 2 * R + t]) stm(m0, j, zt);
             }
             // pt'(j) = b pt - D (mu + alpha), beta = a pt',  j = i0 + r + t
 #pragma unroll
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     pt.v[q] = bv * cur.o1[t].v[q] - d;
                     Pw[2 * R + t].v[q] = av * pt.v[q];
                 }
-                if (act && inb(j)) stm(m1, j, pt);
+                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + R + t]) stm(m1, j, pt);
             }
             // term(i) = E alpha - D beta
             if (out)
@@ -658,18 +667,18 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     }
                     add.v[q] = cur.c[t].v[q] * (e2 - db);
                 }
-                if (act && out && i < ie) {
+                if (!(PML_LINE_ABLATE & 2) && act && out && i < ie) {
                     V un = cur.up[t];
 #pragma unroll
                     for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
                     stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
-                    if (p.v) {
+                    if constexpr (HV) {
                         V w = cur.vv[t];
 #pragma unroll
                         for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
                         stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
                     }
-                    if (p.q_out) {
+                    if constexpr (HQ) {
                         V w = cur.qq[t];
 #pragma unroll
                         for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
@@ -705,33 +714,27 @@ int pml_line_axes(const GridDesc &g, int npml) {
     return axes;
 }
 
-template <typename T, int R, int D, int VL>
-static void launch_pml_line_vl(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
-    static const bool plain = getenv("FWI_PML_LINES_PLAIN") != nullptr;  // A/B hook: no streaming hints
+// 8-byte lanes for fp32, 16-byte for fp64 (256^3 / npml 16 forward, us/step: 4-byte lanes 103-106, 8-byte 99-101,
+// 16-byte 110); the optional operands (v' of the increment form, q of a store sweep) are compile-time: as run-time
+// branches around their loads and stores they were a third of the loop's instructions.
+template <typename T, int R, int D, bool REV>
+static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s) {
+    constexpr int VL = 2;
     const int n = D == 0 ? g.nz : g.ny, no = D == 0 ? g.ny : g.nz;
     const int nxv = g.cx / VL;
     const int bx = nxv <= 16 ? 16 : nxv <= 32 ? 32 : 64, by = 256 / bx;
     const dim3 block(bx, by);
     const dim3 grid((nxv + bx - 1) / bx, (no + by - 1) / by, n < 2 * p.npml + 3 * R ? 1 : 2);
-    if (reverse) {
-        if (plain) hipLaunchKernelGGL((pml_line<T, R, D, true, false, VL>), grid, block, 0, s, p, g);
-        else hipLaunchKernelGGL((pml_line<T, R, D, true, true, VL>), grid, block, 0, s, p, g);
-    } else {
-        if (plain) hipLaunchKernelGGL((pml_line<T, R, D, false, false, VL>), grid, block, 0, s, p, g);
-        else hipLaunchKernelGGL((pml_line<T, R, D, false, true, VL>), grid, block, 0, s, p, g);
-    }
+    if (p.v && p.q_out) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, true, true>), grid, block, 0, s, p, g);
+    else if (p.v) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, true, false>), grid, block, 0, s, p, g);
+    else if (p.q_out) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, false, true>), grid, block, 0, s, p, g);
+    else hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, false, false>), grid, block, 0, s, p, g);
 }
 
-// Lane width: the march is a serial chain per thread (blocks x (arithmetic + one round trip)), so what counts is how
-// many waves share it -- 16-byte lanes make 512 waves at 256^3 (half the SIMDs idle), 4-byte lanes 2048.
 template <typename T, int R, int D>
 static void launch_pml_line_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
-    static const int vl_env = getenv("FWI_PML_LINES_VL") ? atoi(getenv("FWI_PML_LINES_VL")) : 0;
-    constexpr int VMAX = (int)(16 / sizeof(T));
-    const int vl = vl_env ? vl_env : 2;  // (256^3 / npml 16, forward, us/step: 4-byte lanes 103-106, 8-byte 99-101, 16-byte 110)
-    if (vl >= VMAX) launch_pml_line_vl<T, R, D, VMAX>(g, p, reverse, s);
-    else if (vl == 2) launch_pml_line_vl<T, R, D, 2>(g, p, reverse, s);
-    else launch_pml_line_vl<T, R, D, 1>(g, p, reverse, s);
+    if (reverse) launch_pml_line_rev<T, R, D, true>(g, p, s);
+    else launch_pml_line_rev<T, R, D, false>(g, p, s);
 }
 
 template <typename T, int R>
