@@ -8,7 +8,7 @@ O=$R/gpurun_out/r03
 PART=${1:-all}
 mkdir -p $O
 cd $R
-LEGS="headline hbm gradient gradient_increment cfg2 cfg2_cpml cpml3d fp64 point bf16"
+LEGS=${LEGS:-"headline hbm gradient gradient_increment cfg2 cfg2_cpml cpml3d fp64 point bf16"}
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, rocprof args..., -- bench args
   local name=$1; shift
