@@ -440,7 +440,12 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     const int seg = blockIdx.z;
     const int ib = (merged || seg == 0) ? 0 : n - npml - R;
     const int ie = (merged || seg == 1) ? n : npml + R;
-    const int is = ib - W;                // first (warm-up) block
+    // First (warm-up) block: W cells ahead serve any case, but the blocks that would only form zeros are skipped when the
+    // block size divides r (O(8)): the first psi' a segment needs is its border's first row (forward: formed r cells
+    // ahead, adjoint alpha: 2 r), and at the high border everything before the border is zero by the table -- so the
+    // forward march starts r cells ahead of the low border and AT the high segment's first cell, the adjoint 2 r / r ahead
+    const bool high = !merged && seg == 1;
+    const int is = (R % BS == 0) ? ib - (REV ? (high ? R : 2 * R) : (high ? 0 : R)) : ib - W;
     const int c0 = is - R;                // grid row of table entry 0
     const int nrows = (ie - is + BS - 1) / BS * BS + 3 * R + BS;
     for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < nrows && i < MAXC; i += blockDim.x * blockDim.y) {
