@@ -406,8 +406,8 @@ def main():
                            "hints do not exempt it), so this is an HBM-regime run: algorithmic 369 MB at the ~5.5 TB/s "
                            "the 512^3 run sustains = 67 us is the floor of a fully fused step.  One time step = the step "
                            "kernel with the x border's recursion in its lanes + ONE line launch each for the z and the y "
-                           "border (fwi_pml.hip pml_line: they re-read u, C and read-modify-write u' of their border, "
-                           "78 MB each, which is where the distance to that floor is); `kernel_avg_us` is the whole "
+                           "border (fwi_pml.hip pml_line: they re-read u, C and read-modify-write u' of their border, ~"
+                           "78 MB each by the code's byte count, 99 by the counters: that is where the distance to the floor is); `kernel_avg_us` is the whole "
                            "step" % w.npml,
                            extra_bytes=mv)
         r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
