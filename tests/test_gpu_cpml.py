@@ -173,6 +173,40 @@ def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
     assert e_sponge > 0.05 and e_cpml < 2e-3
 
 
+def _cpml_vs_c_oracle(w, nt, alpha, kern):
+    wav = w.wavelet(np.float64)[:nt]
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml, abc="cpml", pml_alpha_max=alpha)
+    d = p.forward(w.src_idx, wav, w.rec_idx, save=True)
+    r = 0.7 * d + 0.2 * np.roll(d, 3, axis=0)
+    a = p.adjoint(r)
+    g = p.gradient("velocity")
+    p.q_store = None
+    with Engine(w.shape, w.h, w.dt, nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max, abc="cpml",
+                pml_alpha_max=alpha) as e:
+        dg = e.forward(w.c, (w.src_idx, wav), w.rec_idx, save=True)
+        assert e.kernel_name == kern
+        ag = e.adjoint(r)
+        gg = e.gradient("velocity")
+    assert rel(dg, d) < TOL32, rel(dg, d)
+    assert rel(ag, a) < 3 * TOL32, rel(ag, a)
+    assert rel(gg, g) < 3 * TOL32, rel(gg, g)
+
+
+def test_cpml_configs1_at_full_size_vs_c_oracle(gpu):
+    """configs[1] as BASELINE.json words it -- 2-D 1024^2 layered model, O(8) stencil + PML (here: the convolutional PML,
+    npml 40, inside the fused 4-step launch) -- at full grid size, 1000 of its 2000 steps: seismograms, F^T r and the
+    gradient of a shared residual against the C oracle."""
+    _cpml_vs_c_oracle(workloads.cfg2(1.0), 1000, 3.14159 * 15.0, "step2d_fused")
+
+
+def test_cpml_3d_lines_and_lanes_at_size_vs_c_oracle(gpu):
+    """3-D 160^3 heterogeneous model, npml 16, 400 steps: the x border in step3d_stream's lanes, the z and y borders as
+    line launches (several workgroup tiles, all four z chunks, two segments per line) against the C oracle."""
+    w = workloads.cfg5(0.625, nshots=1)
+    w.npml = 16
+    _cpml_vs_c_oracle(w, 400, 3.14159 * 10.0, "step3d_stream")
+
+
 @pytest.mark.parametrize("shape,npml", [((130, 250), 16), ((1130, 1070), 40)])
 def test_cpml_fused_launch_is_reproducible_run_to_run(gpu, shape, npml):
     """Tiles read the memory variables of border cells in their halo, which a neighbouring tile owns: the launch writes
