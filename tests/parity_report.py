@@ -23,16 +23,19 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def case(name, w, nt=None, dtype="float32", kernel="auto", **engine_kw):
+def case(name, w, nt=None, dtype="float32", kernel="auto", npml=None, **engine_kw):
     if nt:
         w.nt = nt
+    if npml is not None:
+        w.npml = npml
+    okw = {k: engine_kw[k] for k in ("abc", "pml_alpha_max") if k in engine_kw}  # options that change the SCHEME
     wav = w.wavelet(np.float64)
     src = w.src_idx[:1]
     c0 = w.c_init if w.c_init is not None else w.c * (1.0 + 0.03 * np.sin(np.indices(w.shape).sum(0) / 9.0))
     t0 = time.time()
-    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml)
+    p = CPropagator(w.c, w.h, w.dt, w.order, w.npml, **okw)
     d_obs = p.forward(src, wav, w.rec_idx, save=False)
-    p0 = CPropagator(c0, w.h, w.dt, w.order, w.npml, sigma_max=p.sigma_max)
+    p0 = CPropagator(c0, w.h, w.dt, w.order, w.npml, sigma_max=p.sigma_max, **okw)
     d0 = p0.forward(src, wav, w.rec_idx)
     r = d0 - d_obs
     a0 = p0.adjoint(r)
@@ -75,6 +78,13 @@ def main():
         case("cfg4 128^3 x500 increment", workloads.cfg4(0.5), update_form="increment"),
         case("cfg5 64^3 x250 increment", workloads.cfg5(0.25), update_form="increment"),
         case("cfg5 128^3 x500 increment", workloads.cfg5(0.5), update_form="increment"),
+        # the convolutional PML (round 3: inside the fused 2-D launch; 3-D: x border in the lanes, z / y line launches)
+        case("cfg2 1024^2 x2000 (full) cpml", workloads.cfg2(1.0), abc="cpml", pml_alpha_max=47.0),
+        case("cfg2 1000^2 x1000 cpml (seam tiling)", workloads.cfg2(0.9765625), nt=1000, npml=40, abc="cpml", pml_alpha_max=47.0),
+        case("cfg5 128^3 x500 cpml npml 16", workloads.cfg5(0.5), npml=16, abc="cpml", pml_alpha_max=31.0),
+        case("cfg5 128^3 x500 cpml npml 16 increment", workloads.cfg5(0.5), npml=16, abc="cpml", pml_alpha_max=31.0,
+             update_form="increment"),
+        case("cfg5 128^3 x500 cpml npml 16 fp64", workloads.cfg5(0.5), npml=16, dtype="float64", abc="cpml", pml_alpha_max=31.0),
     ]
     if len(sys.argv) > 1:
         json.dump(rows, open(sys.argv[1], "w"), indent=1)
