@@ -301,6 +301,7 @@ struct Impl {
         a.zp_on = 0;
         a.zp_psi = a.zp_zeta = nullptr;
         a.xp_mode = 0;
+        a.xp_partial = 0;
         a.xp_psi = a.xp_zeta = nullptr;
         a.xp_a = a.xp_b = nullptr;
         for (int k = 0; k < 5; ++k) a.xp_dk[k] = a.xp_dk1[k] = T(0);
@@ -939,6 +940,7 @@ struct Impl {
                 if (ctx->xpml) {  // ... the x border's inside the step kernel itself (step3d_stream, XP)
                     axes = 3;
                     a.xp_mode = dn < 0 ? 2 : 1;
+                    a.xp_partial = ctx->cfg.npml % 4 != 0;
                     a.xp_psi = p.psi[2];
                     a.xp_zeta = p.zeta[2];
                     a.xp_a = p.a[2];
@@ -1639,7 +1641,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // The z border on the z march is opt-in (FWI_STREAM_ZPML=1) since the line launches exist: it saves the z line
     // launch (~21 us at 256^3 / npml 16) but costs the step kernel more than that (58 -> 84 us: the border planes all
     // fall to the first and last z chunk, whose workgroups then decide the launch): forward 106 against 99 us/step.
-    if (ctx->xpml && !ctx->inc && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
+    if (ctx->xpml && !ctx->inc && cfg->npml % 4 == 0 && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
         ctx->zpml_fwd = stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, false);
         // the adjoint's form (two rings, 22 planes of LDS per thread column, ~100 registers parked in AGPRs) is slower
         // than the slab launches it replaces (256^3: step kernel 65 -> 125 us against 28 us of slabs): opt-in only

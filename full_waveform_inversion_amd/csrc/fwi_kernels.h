@@ -59,6 +59,7 @@ struct StepArgs {
     // forward recursion, 2 = its transpose): memory variables in the slab kernels' layout (nz, ny, 2 npml), 1-D
     // coefficients over x, first-difference weights dk (of a memory variable) / dk1 (of the field), see PmlArgs.
     int xp_mode;
+    int xp_partial;  // npml % 4 != 0: the kernel variant with masked stores in the lane astride the border's inner edge
     T *xp_psi, *xp_zeta;
     const T *xp_a, *xp_b;
     T xp_dk[5], xp_dk1[5];

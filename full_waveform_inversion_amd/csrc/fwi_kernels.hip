@@ -283,9 +283,14 @@ constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge]
 // further than 2r from a border pay nothing but two clamped loads -- and holds no global LOAD (the pipelined loop keeps
 // its counted vmcnt).  Chunk seams must stay 2r planes clear of the borders (stream_zpml_supported).
 template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false,
-          bool QB = false, int XP = 0, bool ZP = false>
+          bool QB = false, int XPM = 0, bool ZP = false>
 __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
                                                          int nxt, int nyt, int nblk, int tw) {
+    // XPM 1 / 2: the x border in the lanes, forward / adjoint; 3 / 4: the same for a border whose width is not a
+    // multiple of the lane vector (npml = 10, 14, ...): the one lane per side that straddles the border's inner edge
+    // stores its memory variables cell by cell (the slab row holds the other side's cells right behind)
+    constexpr int XP = XPM == 0 ? 0 : ((XPM - 1) & 1) + 1;
+    constexpr bool XMASK = XPM > 2;
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
     constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
     constexpr int LROWS = TY + 2 * R + 1;
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     V xca, xcb;
     unsigned xld = 0;
     bool xin = false;
+    unsigned xcells = 0;  // (XMASK) which of the lane's cells are border cells
     int64_t xplane = 0;
     if constexpr (XP != 0) {
         const int nsl = 2 * a.npml;
@@ -394,8 +400,9 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             xca.v[j] = b ? a.xp_a[x] : T(0);
             xcb.v[j] = b ? a.xp_b[x] : T(0);
             in |= b;
+            xcells |= b ? 1u << j : 0u;
         }
-        xin = act && in;  // (npml and nx are multiples of VL here: a lane's cells are all in the border or all out)
+        xin = act && in;  // (XMASK off: npml and nx are multiples of VL, a lane's cells are all in the border or all out)
         const int jx = x0 < a.npml ? x0 : x0 - (g.nx - nsl);
         xld = (unsigned)((int64_t)min(y, g.ny - 1) * nsl + (xin ? jx : 0));  // lanes off the border re-read column 0
     }
@@ -818,7 +825,14 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     un.v[j] = (T(2) * X[HALO + j] - up[cur].v[j]) + q.v[j];
             }
             if constexpr (XP != 0) {
-                if (xin) {
+                if (XMASK && xin && xcells != (1u << VL) - 1u) {  // the lane astride the border's inner edge
+#pragma unroll
+                    for (int j = 0; j < VL; ++j)
+                        if (xcells >> j & 1u) {
+                            a.xp_psi[(int64_t)z * xplane + xld + j] = xn0.v[j];
+                            a.xp_zeta[(int64_t)z * xplane + xld + j] = xn1.v[j];
+                        }
+                } else if (xin) {
                     stv<T>(a.xp_psi + (int64_t)z * xplane + xld, xn0);
                     stv<T>(a.xp_zeta + (int64_t)z * xplane + xld, xn1);
                 }
@@ -1001,7 +1015,10 @@ bool stream_supported(const GridDesc &g, bool is_f32) {
 
 bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32) {
     if (g.ndim != 3 || !is_f32 || g.r != 4 || npml < 4) return false;
-    if (npml % 4 || g.nx % 4) return false;            // a lane's four cells lie wholly inside or outside the border
+    // (a lane's four cells lie wholly inside or outside the border when npml % 4 == 0; an even npml leaves one lane per
+    // side astride the inner edge, whose stores are masked (stream_xpml_partial); the high side's lanes stay 16-byte
+    // aligned in the slab row because nx - 2 npml is a multiple of 4)
+    if (npml % 2 || g.nx % 4) return false;
     if (g.nx < 2 * (npml + g.r)) return false;         // the two borders (and their reach) do not meet
     const int tw = t.tile_x, nxt = stream_nxt(g, tw);
     // each border and the r cells it reaches into lie inside ONE tile row, i.e. inside one wave
@@ -1099,7 +1116,7 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
     if constexpr (std::is_same<T, float>::value) {
         if (a.v) {  // increment form (fp32 only; the adjoint sweep images one pairing per step)
             if constexpr (R == 4 && !DAMP) {
-                if (a.xp_mode == 1) {  // ... with the x border's recursion in the lanes (the term joins q, hence v' and u')
+                if (a.xp_mode == 1 && !a.xp_partial) {  // ... with the x border's recursion in the lanes (the term joins q, hence v' and u')
                     if (a.q_out)
                         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true, false, 1>), grid, block, 0, s,
                                            a, g, zchunk, nxt, nyt, nblk, tw);
@@ -1108,12 +1125,30 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
                                            a, g, zchunk, nxt, nyt, nblk, tw);
                     return hipGetLastError();
                 }
-                if (a.xp_mode == 2) {
+                if (a.xp_mode == 2 && !a.xp_partial) {
                     if (a.q_in)
                         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true, false, 2>), grid, block, 0, s,
                                            a, g, zchunk, nxt, nyt, nblk, tw);
                     else
                         hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 2>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    return hipGetLastError();
+                }
+                if (a.xp_mode == 1) {  // (border width not a multiple of 4: masked stores)
+                    if (a.q_out)
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true, false, 3>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    else
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 3>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    return hipGetLastError();
+                }
+                if (a.xp_mode == 2) {
+                    if (a.q_in)
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true, false, 4>), grid, block, 0, s,
+                                           a, g, zchunk, nxt, nyt, nblk, tw);
+                    else
+                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 4>), grid, block, 0, s,
                                            a, g, zchunk, nxt, nyt, nblk, tw);
                     return hipGetLastError();
                 }
@@ -1170,7 +1205,7 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
                 return hipGetLastError();
             }
         }
-        if (a.xp_mode == 1) {  // x-border CPML in the lanes, forward recursion
+        if (a.xp_mode == 1 && !a.xp_partial) {  // x-border CPML in the lanes, forward recursion
             if (a.q_out)
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1>), grid, block, 0, s,
                                    a, g, zchunk, nxt, nyt, nblk, tw);
@@ -1179,7 +1214,7 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
                                    a, g, zchunk, nxt, nyt, nblk, tw);
             return hipGetLastError();
         }
-        if (a.xp_mode == 2) {  // ... its transpose (the adjoint sweep)
+        if (a.xp_mode == 2 && !a.xp_partial) {  // ... its transpose (the adjoint sweep)
             if (a.q_in && a.q_in2)
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 2>), grid, block, 0, s,
                                    a, g, zchunk, nxt, nyt, nblk, tw);
@@ -1188,6 +1223,27 @@ static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, in
                                    a, g, zchunk, nxt, nyt, nblk, tw);
             else
                 hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 2>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+        if (a.xp_mode == 1) {  // ... borders of 10, 14, ... cells: masked stores in the straddling lane
+            if (a.q_out)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 3>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 3>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            return hipGetLastError();
+        }
+        if (a.xp_mode == 2) {  // ... its transpose (the adjoint sweep)
+            if (a.q_in && a.q_in2)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 4>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else if (a.q_in)
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 4>), grid, block, 0, s,
+                                   a, g, zchunk, nxt, nyt, nblk, tw);
+            else
+                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 4>), grid, block, 0, s,
                                    a, g, zchunk, nxt, nyt, nblk, tw);
             return hipGetLastError();
         }

@@ -37,6 +37,10 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((24, 16, 256), 8, 16, 20.0, "float32", TOL32, "step3d_stream", {}),          # full 256-column tiles (FULL path)
     ((30, 24, 40), 8, 12, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 7}), # several z chunks per tile
     ((40, 36, 64), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"update_form": "increment"}),  # ... in increment form
+    # ... border widths that are even but not multiples of 4: one lane per side astride the border's inner edge (masked stores)
+    ((40, 36, 64), 8, 10, 30.0, "float32", TOL32, "step3d_stream", {}),
+    ((36, 30, 300), 8, 14, 0.0, "float32", TOL32, "step3d_stream", {"update_form": "increment", "ckpt_interval": 16}),
+    ((26, 22, 256), 8, 6, 20.0, "float32", TOL32, "step3d_stream", {}),           # (FULL path)
     # grids on which the z border can ride on the z march as well (stream_zpml_supported; opt-in, see
     # test_cpml_z_border_on_the_march) -- by default their z and y borders run as line launches
     ((64, 20, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": 32}),   # a seam between the two borders
