@@ -398,13 +398,13 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
 // LINE form of the z / y border (3-D): one launch per axis and time step instead of three slab passes.
 //
 // Along its own axis the border recursion is one-dimensional: psi'(i), zeta'(i) and the term of cell i need the field
-// and the memory variables of the SAME (other two coordinates) line only.  So a thread owns one 16-byte lane of x at a
-// fixed other coordinate and marches along the axis through the border and the r cells its term reaches, in blocks of
+// and the memory variables of the SAME (other two coordinates) line only.  So a thread owns one lane of x (two cells: 8
+// bytes in fp32, 16 in fp64 -- measured best, DESIGN.md s.4 CPML) at a fixed other coordinate and marches along the axis through the border and the r cells its term reaches, in blocks of
 // four cells: the field values of the line sit in a register window (every u is loaded once instead of 2r + 1 times),
 // the new psi' (adjoint: alpha = a zt', beta = a pt') in a second one -- they are never re-read from memory, which is
 // what forced the slab form into three passes -- and every memory variable is read once and written once per step,
 // with streaming hints: at 256^3 the six of them (50 MB) are what pushed the wavefields out of the Infinity Cache.
-// The inputs of block k + 1 are in flight while block k is computed.  All accesses are 16 bytes per lane along x.
+// The inputs of block k + 1 are in flight while block k is computed.  All accesses are coalesced along x.
 // Off the border a = b = 0 make psi' = zeta' = 0 by themselves, so one loop body serves the low border, the high
 // border and the case of the two (nearly) meeting (n < 2 npml + 3 r: one segment over the whole axis); loads are clamped
 // instead of branched around, stores predicated.  Runs AFTER the step kernel: reads u^n (adjoint: the newest mu) and
@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
 template <typename T, int R, int D, bool REV, int VL, bool HV, bool HQ>
 __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     constexpr bool NT = true;  // (streaming hints on the memory variables: read once, written once per step)
-    // cells per block = the loads a thread keeps in flight (5-7 per cell): 4-byte lanes take twice the cells to have
-    // the same bytes per wave on the way while a block is computed, and half the round trips per line
+    // cells per block = the loads a thread keeps in flight (5-7 per cell).  (4-byte lanes with 8 cells per block were
+    // measured too: no faster; only VL = 2 is instantiated)
     constexpr int BS = VL == 1 ? PML_LINE_BS1 : 4;
     constexpr int W = (2 * R + BS - 1) / BS * BS;  // warm-up cells ahead of the segment (whole blocks)
     constexpr int NU = BS + 3 * R, NP = BS + 2 * R;
