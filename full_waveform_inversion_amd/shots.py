@@ -132,7 +132,9 @@ class EnginePool:
     context and is driven by its own host thread (ctypes releases the GIL during the C-ABI calls).  Measured
     on configs[2] (32 shots of 1024^2 x 2000 steps, forward + adjoint + imaging): 0.44 s one after the other,
     0.35 s with two contexts, 0.35 - 0.38 s with three to six, 1.06 s with eight -- more streams than the
-    runtime has hardware queues for serialise and pay for it; hence ``MAX_USEFUL``.  3-D shots are
+    runtime has hardware queues for serialise and pay for it; hence ``MAX_USEFUL``.  With the convolutional PML
+    (``abc="cpml"``) a 1024^2 launch ends on its four corner tiles, and the overlap is what fills the idle CUs: 1.01 s
+    one after the other, 0.65 s with two contexts, **0.55 s with three**, 1.24 s with four (round 3).  3-D shots are
     bandwidth-bound: use a pool of one.  Engines after the first only add into the first one's gradient
     accumulator, which also owns the RCCL communicator.
     """

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--host-lbfgs", action="store_true", help="keep the optimiser vectors on the host")
     ap.add_argument("--pool", type=int, default=0,
                     help="engines sharing this GPU's shots concurrently; 0 = auto (2 in 2-D, 1 in 3-D)")
+    ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"], help="absorbing border (fwi_config.abc)")
     ap.add_argument("--image-stride", type=int, default=1,
                     help="imaging condition every S-th step (fwi_config.image_stride)")
     a = ap.parse_args()
@@ -41,11 +42,12 @@ def main():
     w = workloads.CONFIGS[a.config](a.scale, **kw)
     wav = w.wavelet()
     shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(len(w.src_idx))]
-    psize = a.pool or (2 if w.ndim == 2 else 1)
+    psize = a.pool or ((3 if a.abc == "cpml" else 2) if w.ndim == 2 else 1)  # (measured: shots.EnginePool)
     from full_waveform_inversion_amd import default_sigma_max
     sigma = default_sigma_max(float(w.c.max()), w.h, w.npml)
     pool = sh.EnginePool(lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
-                                        sigma_max=sigma, image_stride=a.image_stride), psize)
+                                        sigma_max=sigma, image_stride=a.image_stride, abc=a.abc,
+                                        pml_alpha_max=(3.14159 * w.f0 if a.abc == "cpml" else 0.0)), psize)
     e = pool.primary
     ex = sh.NoExchange()
     rdzv = None
