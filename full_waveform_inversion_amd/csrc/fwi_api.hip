@@ -1438,6 +1438,14 @@ int create_impl(fwi_ctx *ctx) {
     HIPCHK(ctx, hipMalloc(&ctx->dy, (size_t)g.ny * es));
     HIPCHK(ctx, hipMalloc(&ctx->dx, (size_t)g.nx * es));
     HIPCHK(ctx, hipMalloc((void **)&ctx->red, 64));
+    if (ctx->fused2d) {  // tile order of the fused 2-D kernel on grids of more than one round of tiles (on THIS device)
+        std::vector<int> order;
+        fused2d_tile_order(g, ctx->fused_ft, c.npml, order, ctx->cpml ? 1 : 0);
+        if (!order.empty()) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->fused_order, order.size() * sizeof(int)));
+            HIPCHK(ctx, hipMemcpy(ctx->fused_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     double sm = c.sigma_max;
     const int np_sponge = ctx->cpml ? 0 : c.npml;  // with the CPML the damping factors are off (A = B = 1)
     profile(ctx->pz, g.nz, np_sponge, sm, c.dt);
@@ -1615,14 +1623,6 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->fused2d = cfg->ndim == 2 && cfg->dtype == FWI_F32 && (!ctx->cpml || cpml_in_launch) && !getenv("FWI_NO_FUSED2D") &&
                    (ctx->inc ? cfg->kernel == FWI_KERNEL_AUTO : ctx->kernel == K_STREAM);
     if (ctx->fused2d && !ctx->cpml && !ctx->inc) ctx->fused_ft = fused2d_pick_tile(ctx->gd);
-    if (ctx->fused2d) {
-        std::vector<int> order;
-        fused2d_tile_order(ctx->gd, ctx->fused_ft, cfg->npml, order, ctx->cpml ? 1 : 0);
-        if (!order.empty()) {
-            HIPCHK(ctx, hipMalloc((void **)&ctx->fused_order, order.size() * sizeof(int)));
-            HIPCHK(ctx, hipMemcpy(ctx->fused_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
-        }
-    }
     // 3-D fp32 stream contexts: two time steps per pass for forward sweeps without imaging (FWI_STREAM_PAIR=0 /
     // =1 is the tuning / comparison hook)
     if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {
