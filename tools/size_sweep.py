@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--shapes", default="", help="explicit shapes instead of cubes / squares, e.g. 200x400x400,128x512x512")
     ap.add_argument("--npml", type=int, default=16)
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"])
+    ap.add_argument("--nt", type=int, default=0, help="time steps per run (0 = by size, 16 .. 400: short runs see a grid that is "
+                    "still mostly zeros and read a few % high, DESIGN.md s.4; 1000+ for figures to quote)")
     a = ap.parse_args()
     if a.sizes:
         sizes = [int(s) for s in a.sizes.split(",")]
@@ -58,7 +60,7 @@ def main():
         shapes = [tuple(int(v) for v in sh.split("x")) for sh in a.shapes.split(",")]
     for shape in shapes:
         npts = float(np.prod(shape))
-        nt = max(16, min(400, int(4e9 / npts))) // 4 * 4
+        nt = a.nt if a.nt > 0 else max(16, min(400, int(4e9 / npts))) // 4 * 4
         if a.mode == "gradient":  # the forward-term store must fit
             nt = max(8, min(nt, int(100e9 / (4.0 * npts)))) // 4 * 4
         print(json.dumps(rate(shape, nt, min(a.npml, min(shape) // 4), a.mode)), flush=True)
