@@ -32,7 +32,15 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     g.nx = nx;
     g.r = order / 2;
     const int hy = (ndim == 3) ? HALO : 0;
-    g.sy = HALO + round_up(nx, XALIGN) + HALO;
+    // x pitch.  2-D: rounded to XALIGN, step2d_tile's 256-column tiles load whole rows.  3-D: TIGHT (XALIGN3D): the stream
+    // kernel clamps every lane's address into [0, nx] + the halo, so nothing needs the slack -- and the unused bytes between
+    // rows cost up to a quarter of the HBM-regime rate (round 3: 512 x 512 x 384 280 -> 354 Gpts/s, 448^3 299 -> 351, 640^3
+    // 293 -> 333, 320^3 266 -> 314..333, 272^3 277 -> 318, 384^3 289 -> 305..318; 256-multiples unchanged).
+    // FWI_XALIGN3D is the A/B hook.
+    int xal = ndim == 3 ? XALIGN3D : XALIGN;
+    if (ndim == 3)
+        if (const char *e = getenv("FWI_XALIGN3D")) xal = std::max(4, atoi(e) / 4 * 4);
+    g.sy = HALO + round_up(nx, xal) + HALO;
     const int64_t py = (ndim == 3) ? HALO + round_up(g.ny, YALIGN) + HALO : 1;
     g.sz = g.sy * py;
     g.off0 = (int64_t)HALO * g.sz + (int64_t)hy * g.sy + HALO;
