@@ -40,14 +40,21 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     int xal = ndim == 3 ? XALIGN3D : XALIGN;
     if (ndim == 3)
         if (const char *e = getenv("FWI_XALIGN3D")) xal = std::max(4, atoi(e) / 4 * 4);
-    g.sy = HALO + round_up(nx, xal) + HALO;
+    // ... and in 3-D the HALO cells right of a row ARE the HALO cells left of the next one (both are zeros that nothing
+    // writes): pitch = nx + 4.  Every float of pitch beyond the data costs: 512^3 at pitch nx + 8 / 16 / 24 / 32 / 64 /
+    // 128 / 256: 350 / 340 / 317 / 305 / 292 / 287 / 276 Gpts/s; nx + 4 against nx + 8: 256^3 424 -> 434, 384^3 301 -> 305.
+    g.sy = HALO + round_up(nx, xal) + (ndim == 3 ? 0 : HALO);
+    if (ndim == 3)
+        if (const char *e = getenv("FWI_XPITCH_EXTRA")) g.sy += std::max(0, atoi(e) / 4 * 4);  // A/B hook (floats)
+    // (rows whose interior starts on a 128-byte line -- pitch nx + 32 with the gap shared as right / left halo -- were
+    // measured as well: 256^3 +2 %, 512^3 +1 %, 640^3 -8 %: not adopted)
     const int64_t py = (ndim == 3) ? HALO + round_up(g.ny, YALIGN) + HALO : 1;
     g.sz = g.sy * py;
     g.off0 = (int64_t)HALO * g.sz + (int64_t)hy * g.sy + HALO;
     // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D.
     // 3-D: LOOKAHEAD extra zero planes behind the far z halo, so the stream kernel's prefetches of
     // planes z + r + 1 ... need no clamping (affine addresses: the plane offsets strength-reduce).
-    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO);
+    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO) + HALO;  // (+ the last row's right halo)
     g.cx = (int)round_up(nx, 4);
     g.npts = (int64_t)nz * g.ny * g.cx;
     return g;
