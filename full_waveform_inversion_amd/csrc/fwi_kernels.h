@@ -11,10 +11,9 @@ namespace fwi {
 // Layout halo of every padded field: 4 cells on each side of every stencil
 // axis, whatever the order (4 floats = 16 B keeps interior rows float4-aligned).
 constexpr int HALO = 4;
-// Padded extents: x to XALIGN cells in 2-D (whole 256-column tile rows) and to XALIGN3D in 3-D (the stream kernel
-// clamps its addresses; slack between rows costs HBM efficiency), y to YALIGN rows.
-constexpr int XALIGN = 256;   // 2-D fields
-constexpr int XALIGN3D = 16;  // 3-D fields (make_grid)
+// Padded extents: x to XALIGN cells plus one shared halo (tight rows: slack between rows costs HBM efficiency, make_grid),
+// y to YALIGN rows.
+constexpr int XALIGN = 16;
 constexpr int YALIGN = 16;
 // Zero planes appended behind the far z halo of 3-D fields: the stream kernel reads up to
 // r + PF (<= 4 + 3) planes past the last interior plane without clamping.

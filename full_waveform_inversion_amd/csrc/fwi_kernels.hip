@@ -32,20 +32,16 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     g.nx = nx;
     g.r = order / 2;
     const int hy = (ndim == 3) ? HALO : 0;
-    // x pitch.  2-D: rounded to XALIGN, step2d_tile's 256-column tiles load whole rows.  3-D: TIGHT (XALIGN3D): the stream
-    // kernel clamps every lane's address into [0, nx] + the halo, so nothing needs the slack -- and the unused bytes between
-    // rows cost up to a quarter of the HBM-regime rate (round 3: 512 x 512 x 384 280 -> 354 Gpts/s, 448^3 299 -> 351, 640^3
-    // 293 -> 333, 320^3 266 -> 314..333, 272^3 277 -> 318, 384^3 289 -> 305..318; 256-multiples unchanged).
-    // FWI_XALIGN3D is the A/B hook.
-    int xal = ndim == 3 ? XALIGN3D : XALIGN;
-    if (ndim == 3)
-        if (const char *e = getenv("FWI_XALIGN3D")) xal = std::max(4, atoi(e) / 4 * 4);
-    // ... and in 3-D the HALO cells right of a row ARE the HALO cells left of the next one (both are zeros that nothing
-    // writes): pitch = nx + 4.  Every float of pitch beyond the data costs: 512^3 at pitch nx + 8 / 16 / 24 / 32 / 64 /
-    // 128 / 256: 350 / 340 / 317 / 305 / 292 / 287 / 276 Gpts/s; nx + 4 against nx + 8: 256^3 424 -> 434, 384^3 301 -> 305.
-    g.sy = HALO + round_up(nx, xal) + (ndim == 3 ? 0 : HALO);
-    if (ndim == 3)
-        if (const char *e = getenv("FWI_XPITCH_EXTRA")) g.sy += std::max(0, atoi(e) / 4 * 4);  // A/B hook (floats)
+    // x pitch: TIGHT -- nx rounded to XALIGN (16) plus ONE halo: the HALO zero cells right of a row are the HALO cells left
+    // of the next (nothing writes them).  Every kernel clamps its lanes' addresses into [0, nx] + the halo, so no tile needs
+    // slack, and the unused bytes between rows are expensive: until round 3 rows were 4 + roundup(nx, 256) + 4 floats, which
+    // cost the 3-D sizes that are not multiples of 256 up to a quarter of their HBM-regime rate (512 x 512 x 384 280 -> 354
+    // Gpts/s, 448^3 299 -> 351, 640^3 293 -> 333, 320^3 266 -> 325, 272^3 277 -> 339, 384^3 289 -> 323).  Pitch sweep at 512^3,
+    // nx + 8 / 16 / 24 / 32 / 64 / 128 / 256 floats: 350 / 340 / 317 / 305 / 292 / 287 / 276 Gpts/s; nx + 4 against nx + 8: 256^3
+    // 424 -> 434, 384^3 301 -> 305.  2-D (cache-resident up to ~4096^2): +1..2 % at every size from 1000^2 to 8192^2.
+    // FWI_XPITCH_EXTRA (floats) is the A/B hook.
+    g.sy = HALO + round_up(nx, XALIGN);
+    if (const char *e = getenv("FWI_XPITCH_EXTRA")) g.sy += std::max(0, atoi(e) / 4 * 4);
     // (rows whose interior starts on a 128-byte line -- pitch nx + 32 with the gap shared as right / left halo -- were
     // measured as well: 256^3 +2 %, 512^3 +1 %, 640^3 -8 %: not adopted)
     // (sharing the y-halo rows between consecutive planes the same way was measured: within noise, 512^3 349 vs 352)
@@ -55,7 +51,8 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D.
     // 3-D: LOOKAHEAD extra zero planes behind the far z halo, so the stream kernel's prefetches of
     // planes z + r + 1 ... need no clamping (affine addresses: the plane offsets strength-reduce).
-    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO) + HALO;  // (+ the last row's right halo)
+    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO) + HALO + 2 * 256;  // (+ the last row's right halo, and
+                                        // the edge loads of a 256-column tile whose row ends early: values never used)
     g.cx = (int)round_up(nx, 4);
     g.npts = (int64_t)nz * g.ny * g.cx;
     return g;
