@@ -13,7 +13,7 @@ namespace fwi {
 constexpr int HALO = 4;
 // Padded extents: x to XALIGN cells plus one shared halo (tight rows: slack between rows costs HBM efficiency, make_grid),
 // y to YALIGN rows.
-constexpr int XALIGN = 16;
+constexpr int XALIGN = 4;
 constexpr int YALIGN = 16;
 // Zero planes appended behind the far z halo of 3-D fields: the stream kernel reads up to
 // r + PF (<= 4 + 3) planes past the last interior plane without clamping.

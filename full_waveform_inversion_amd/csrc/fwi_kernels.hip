@@ -32,7 +32,7 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     g.nx = nx;
     g.r = order / 2;
     const int hy = (ndim == 3) ? HALO : 0;
-    // x pitch: TIGHT -- nx rounded to XALIGN (16) plus ONE halo: the HALO zero cells right of a row are the HALO cells left
+    // x pitch: TIGHT -- nx rounded to XALIGN (4: one 16-byte lane) plus ONE halo: the HALO zero cells right of a row are the HALO cells left
     // of the next (nothing writes them).  Every kernel clamps its lanes' addresses into [0, nx] + the halo, so no tile needs
     // slack, and the unused bytes between rows are expensive: until round 3 rows were 4 + roundup(nx, 256) + 4 floats, which
     // cost the 3-D sizes that are not multiples of 256 up to a quarter of their HBM-regime rate (512 x 512 x 384 280 -> 354
