@@ -12,27 +12,65 @@ import os
 import numpy as np
 
 
-def save_state(path, it, x, f, g, S, Y, log, evals):
+def save_state(path, it, x, f, g, S, Y, log, evals, history=None, bounds=None):
     """Optimiser state after iteration ``it`` (SURVEY.md s.5 "checkpoint / resume": "optimiser state save per L-BFGS
-    iteration"): model, misfit, gradient, the curvature pairs oldest first, the log.  Written to a temporary file and
-    renamed, so an interrupted run never leaves a torn file behind."""
+    iteration"): model, misfit, gradient, the curvature pairs oldest first, the log, and the settings a continuation
+    must share (``history``, ``bounds``).  Written to a temporary file and renamed, so an interrupted run never leaves
+    a torn file behind.  In a multi-rank job only ONE rank should pass a path (every rank holds the same state)."""
     tmp = "%s.tmp.%d.npz" % (path, os.getpid())
     arrays = {"x": np.asarray(x), "g": np.asarray(g)}
     for i, (s, y) in enumerate(zip(S, Y)):
         arrays["s%d" % i] = np.asarray(s)
         arrays["y%d" % i] = np.asarray(y)
+    meta = {"history": None if history is None else int(history),
+            "bounds": None if bounds is None else [float(bounds[0]), float(bounds[1])]}
     np.savez(tmp, it=np.int64(it), f=np.float64(f), evals=np.int64(evals), npairs=np.int64(len(S)),
-             log=np.frombuffer(json.dumps(log).encode(), np.uint8), **arrays)
+             log=np.frombuffer(json.dumps(log).encode(), np.uint8),
+             meta=np.frombuffer(json.dumps(meta).encode(), np.uint8), **arrays)
     os.replace(tmp, path)
 
 
 def load_state(path):
-    """The dict :func:`save_state` wrote: ``it, f, evals, x, g, S, Y, log``."""
+    """The dict :func:`save_state` wrote: ``it, f, evals, x, g, S, Y, log`` (+ ``history``, ``bounds`` when the file
+    holds them)."""
     with np.load(path) as z:
         n = int(z["npairs"])
-        return {"it": int(z["it"]), "f": float(z["f"]), "evals": int(z["evals"]), "x": z["x"].copy(), "g": z["g"].copy(),
-                "S": [z["s%d" % i].copy() for i in range(n)], "Y": [z["y%d" % i].copy() for i in range(n)],
-                "log": json.loads(bytes(z["log"]).decode())}
+        st = {"it": int(z["it"]), "f": float(z["f"]), "evals": int(z["evals"]), "x": z["x"].copy(), "g": z["g"].copy(),
+              "S": [z["s%d" % i].copy() for i in range(n)], "Y": [z["y%d" % i].copy() for i in range(n)],
+              "log": json.loads(bytes(z["log"]).decode())}
+        if "meta" in z.files:
+            st.update(json.loads(bytes(z["meta"]).decode()))
+        return st
+
+
+def _checked_resume(resume, history, bounds, shape=None):
+    """Load and validate a state for continuation: the bit-for-bit promise holds only if the continuation runs with
+    the settings of the run that wrote the file, so differing ``history`` / ``bounds`` (when the file records them)
+    and arrays of the wrong shape are errors, not silent changes; more pairs than ``history`` are trimmed (oldest
+    first), which is what the writing run would have done."""
+    st = load_state(resume) if isinstance(resume, (str, os.PathLike)) else dict(resume)
+    if st.get("history") is not None and int(st["history"]) != int(history):
+        raise ValueError("resume: the state was written with history=%d, this run has history=%d"
+                         % (st["history"], int(history)))
+    if "bounds" in st:
+        b = None if bounds is None else [float(bounds[0]), float(bounds[1])]
+        if st["bounds"] != b:
+            raise ValueError("resume: the state was written with bounds=%r, this run has bounds=%r" % (st["bounds"], b))
+    x = np.asarray(st["x"])
+    if shape is not None and tuple(x.shape) != tuple(shape):
+        raise ValueError("resume: the state holds a model of shape %r, the engine's grid is %r" % (x.shape, tuple(shape)))
+    for name, a in [("g", st["g"])] + [("s%d" % i, s) for i, s in enumerate(st["S"])] + \
+                   [("y%d" % i, y) for i, y in enumerate(st["Y"])]:
+        if np.asarray(a).shape != x.shape:
+            raise ValueError("resume: %s has shape %r, the model %r" % (name, np.asarray(a).shape, x.shape))
+    if len(st["S"]) != len(st["Y"]):
+        raise ValueError("resume: %d s-vectors but %d y-vectors" % (len(st["S"]), len(st["Y"])))
+    st["S"], st["Y"] = list(st["S"])[-int(history):], list(st["Y"])[-int(history):]
+    return st
+
+
+def _search_failed(log):
+    return bool(log) and log[-1].get("note") == "line search failed"
 
 
 def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, c1=1e-4, max_ls=8,
@@ -48,7 +86,8 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
     an FWI misfit has no natural scale).  ``dot(a, b)``: inner product (pass ``Engine.dot``
     for the GPU wave-shuffle reduction).  Returns ``(x, f, log)``.
 
-    ``checkpoint``: path of a state file rewritten after every completed iteration (:func:`save_state`).
+    ``checkpoint``: path of a state file rewritten after every completed iteration (:func:`save_state`); in a
+    multi-rank job pass it on ONE rank only (every rank holds the same state).
     ``resume``: such a path (or the dict of :func:`load_state`): the run continues after the iteration it holds --
     ``x0`` is ignored and no misfit is re-evaluated -- and, ``fg`` being deterministic, reproduces the
     uninterrupted run bit for bit (``maxiter`` counts iterations of the whole run, not of this call).
@@ -62,9 +101,11 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         return np.clip(x, lo, hi) if bounds is not None else x
 
     if resume is not None:
-        st = load_state(resume) if isinstance(resume, (str, os.PathLike)) else resume
+        st = _checked_resume(resume, history, bounds, None if x0 is None else np.shape(x0))
         x, f, g, S, Y = st["x"], st["f"], st["g"], list(st["S"]), list(st["Y"])
         log, evals, it0 = list(st["log"]), st["evals"], st["it"]
+        if _search_failed(log):
+            return x, f, log  # the run ended on a failed search: a continuation would only repeat it
     else:
         x = project(np.array(x0, copy=True))
         f, g = fg(x)
@@ -72,7 +113,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         S, Y, log = [], [], [{"iter": 0, "f": f, "evals": 1}]
         evals, it0 = 1, 0
         if checkpoint:
-            save_state(checkpoint, 0, x, f, g, S, Y, log, evals)
+            save_state(checkpoint, 0, x, f, g, S, Y, log, evals, history, bounds)
     for it in range(it0 + 1, maxiter + 1):
         if not float(np.abs(g).max()) > gtol:
             break  # stationary (or projected onto a bound everywhere)
@@ -114,6 +155,8 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
                 shrunk = True
         if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
+            if checkpoint:  # the terminal entry too: a resumed run must not repeat the failed search
+                save_state(checkpoint, it - 1, x, f, g, S, Y, log, evals, history, bounds)
             break
         t, fn, xn, gn = best
         s, y = xn - x, gn - g
@@ -127,7 +170,7 @@ def lbfgs(fg, x0, maxiter=5, history=5, first_step=None, bounds=None, dot=None, 
         _require_finite(f, float(np.abs(g).max()), dot(g, g), it)
         log.append({"iter": it, "f": f, "evals": evals, "step": t})
         if checkpoint:
-            save_state(checkpoint, it, x, f, g, S, Y, log, evals)
+            save_state(checkpoint, it, x, f, g, S, Y, log, evals, history, bounds)
         if callback:
             callback(it, x, f, g)
     return x, f, log
@@ -176,10 +219,13 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
 
     def save(it, f, log, evals):
         save_state(checkpoint, it, engine.vec_download(X), f, engine.vec_download(G),
-                   [engine.vec_download(s) for s, _ in pairs], [engine.vec_download(y) for _, y in pairs], log, evals)
+                   [engine.vec_download(s) for s, _ in pairs], [engine.vec_download(y) for _, y in pairs], log, evals,
+                   m, bounds)
 
     if resume is not None:
-        st = load_state(resume) if isinstance(resume, (str, os.PathLike)) else resume
+        st = _checked_resume(resume, m, bounds, getattr(engine, "shape", None))
+        if _search_failed(st["log"]):
+            return np.asarray(st["x"]), st["f"], list(st["log"])
         engine.vec_upload(X, st["x"])
         engine.vec_upload(G, st["g"])
         for s_h, y_h in list(zip(st["S"], st["Y"]))[-m:]:
@@ -246,6 +292,8 @@ def lbfgs_device(engine, fg, x0, maxiter=5, history=5, first_step=None, bounds=N
                 shrunk = True
         if best is None:
             log.append({"iter": it, "f": f, "evals": evals, "note": "line search failed"})
+            if checkpoint:
+                save(it - 1, f, log, evals)
             break
         t, fn = best
         XN, XB = XB, XN

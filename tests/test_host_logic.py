@@ -217,6 +217,33 @@ def test_shot_parallel_world2_matches_serial(tmp_path):
         assert np.linalg.norm(r["g"] - g) <= 1e-12 * np.linalg.norm(g)
 
 
+@pytest.mark.parametrize("first_step,branches", [(10.0, False), (3000.0, True)])
+def test_lbfgs_outer_loop_world2_stays_in_lock_step(tmp_path, first_step, branches):
+    """configs[4]'s pattern on two ranks: 5 shots split 3 + 2, three L-BFGS iterations, every rank running the optimiser
+    on the summed gradient.  The ranks' iterates, misfits and line-search logs must be BIT-identical to each other (a
+    line-search decision taken differently on one rank would deadlock or diverge the job) and equal the serial run;
+    `first_step=3000` makes the first trial step fail the Armijo test, so the search branches (backtracking)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _lbfgs_dist_worker as lw
+    out = str(tmp_path / "lb")
+    for rc, o in _spawn_ranks("_lbfgs_dist_worker.py", [out, repr(first_step)], 2):
+        assert rc == 0, o
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    logs = [json.loads(bytes(r["log"]).decode()) for r in res]
+    assert np.array_equal(res[0]["x"], res[1]["x"]) and float(res[0]["f"]) == float(res[1]["f"]) and logs[0] == logs[1]
+    x, f, log = lw.run(first_step)
+    assert np.linalg.norm(res[0]["x"] - x) <= 1e-12 * np.linalg.norm(x) and abs(float(res[0]["f"]) - f) <= 1e-10 * abs(f)
+    assert [(e["iter"], e["evals"]) for e in logs[0]] == [(e["iter"], e["evals"]) for e in log]
+    assert all(abs(a.get("step", 0) - b.get("step", 0)) <= 1e-9 * abs(b.get("step", 0)) for a, b in zip(logs[0], log))
+    assert len(log) == 4 and log[-1]["f"] < 0.5 * log[0]["f"]
+    assert (log[1]["evals"] - log[0]["evals"] > 1 and log[1]["step"] < 1.0) == branches  # the Armijo test failed first
+    # one writer: rank 0's state file is the finished run
+    from full_waveform_inversion_amd.lbfgs import load_state
+    st = load_state(out + ".state.npz")
+    assert st["it"] == 3 and np.array_equal(st["x"], res[0]["x"])
+
+
 def _run_mc_world2(tmp_path, backend):
     out = str(tmp_path / "mc")
     for rc, o in _spawn_ranks("_mc_dist_worker.py", [out, backend], 2):
@@ -296,8 +323,46 @@ def test_lbfgs_state_save_and_resume_reproduce_the_uninterrupted_run(tmp_path):
                          resume=load_state(ck3))
     assert np.array_equal(x3, x_ref) and log3 == log_ref
     # resuming a finished run does nothing
-    x4, f4, log4 = lbfgs(counted, None, maxiter=7, history=3, resume=ck)
+    x4, f4, log4 = lbfgs(counted, None, maxiter=7, history=3, bounds=(-2.0, 2.0), resume=ck)
     assert np.array_equal(x4, x_ref) and log4 == log_ref
+    # the continuation must share the writer's settings -- other history / bounds / shapes are errors
+    assert load_state(ck3)["history"] == 3 and load_state(ck3)["bounds"] == [-2.0, 2.0]
+    with pytest.raises(ValueError, match="history"):
+        lbfgs(counted, None, maxiter=7, history=5, bounds=(-2.0, 2.0), resume=ck3)
+    with pytest.raises(ValueError, match="bounds"):
+        lbfgs(counted, None, maxiter=7, history=3, resume=ck3)
+    with pytest.raises(ValueError, match="shape"):
+        lbfgs(counted, np.zeros(11), maxiter=7, history=3, bounds=(-2.0, 2.0), resume=ck3)
+    st = load_state(ck3)
+    st["S"] = st["S"] + [st["S"][-1][:5]]
+    with pytest.raises(ValueError):
+        lbfgs(counted, None, maxiter=7, history=3, bounds=(-2.0, 2.0), resume=st)
+    # a state written before the settings were recorded (no "history" / "bounds" keys) holding more pairs than this
+    # run's history: trimmed to the newest, oldest first
+    st = {k: v for k, v in load_state(ck3).items() if k not in ("history", "bounds")}
+    calls["n"] = 0
+    lbfgs(counted, None, maxiter=4, history=2, first_step=0.1, max_ls=20, bounds=(-2.0, 2.0), resume=st)
+    assert calls["n"] >= 1
+
+
+def test_lbfgs_checkpoints_a_failed_line_search_and_a_resume_does_not_repeat_it(tmp_path):
+    """a run that ends with "line search failed" writes that terminal log entry too; resuming from the
+    file returns at once instead of repeating max_ls misfit evaluations (each one a sweep over all shots)."""
+    from full_waveform_inversion_amd.lbfgs import load_state
+    calls = {"n": 0}
+
+    def bumpy(x):  # the gradient lies about the slope: no step along -g ever satisfies the Armijo test
+        calls["n"] += 1
+        return float(x @ x), -2.0 * x
+
+    ck = str(tmp_path / "s.npz")
+    x, f, log = lbfgs(bumpy, np.ones(4), maxiter=3, first_step=0.5, max_ls=4, checkpoint=ck)
+    assert log[-1].get("note") == "line search failed" and calls["n"] == 1 + 4
+    st = load_state(ck)
+    assert st["log"] == log and st["it"] == 0 and np.array_equal(st["x"], x)
+    calls["n"] = 0
+    x2, f2, log2 = lbfgs(bumpy, None, maxiter=3, first_step=0.5, max_ls=4, resume=ck)
+    assert calls["n"] == 0 and log2 == log and np.array_equal(x2, x) and f2 == f
 
 
 def test_lbfgs_recovers_from_a_far_too_long_first_step_in_few_evaluations():

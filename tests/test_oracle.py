@@ -268,6 +268,152 @@ def test_observed_convergence_orders():
 
 
 # ---------------------------------------------------------------------------
+# Heterogeneous rung of the ladder: manufactured solutions.  The analytic checks above are homogeneous, and
+# adjointness / finite-difference gradients only show self-consistency; here a smooth u(x, t) = g(t) phi(x) is
+# imposed on a smoothly VARYING c(x), the source term that makes it an exact solution of the continuous equations is
+# evaluated in closed form and injected at every node, and the oracle's field must converge to u at the scheme's
+# orders -- an independent solution for variable C, for the sponge and (further down) for the CPML's coefficients.
+# ---------------------------------------------------------------------------
+_MMS_X, _MMS_TG, _MMS_TEND = 400.0, 0.2, 0.15   # box edge (m), period of g, final time (s)
+
+
+def _sink(t, k):
+    """sin^k(t) and its first two derivatives with respect to t."""
+    s, co = np.sin(t), np.cos(t)
+    return s ** k, k * s ** (k - 1) * co, k * (k - 1) * s ** (k - 2) * co ** 2 - k * s ** k
+
+
+def _mms_medium(n):
+    x = np.arange(n) * (_MMS_X / (n - 1))
+    Z, Xg = np.meshgrid(x, x, indexing="ij")
+    c = 2000.0 * (1 + 0.2 * np.sin(2 * np.pi * Xg / _MMS_X) * np.cos(2 * np.pi * Z / _MMS_X) + 0.1 * Z / _MMS_X)
+    return x, c
+
+
+def _mms_points(n):
+    src = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2)
+    st = max(1, (n - 1) // 20)   # receivers: the nodes of the coarsest level, at every level
+    rec = np.stack(np.meshgrid(np.arange(0, n, st), np.arange(0, n, st), indexing="ij"), -1).reshape(-1, 2)
+    return src, rec, st
+
+
+def _mms_sponge_error(n, order, dt, power=8, sigma_max=150.0, prop=CPropagator):
+    """Relative L2 error over all recorded samples of the 2-D sponge scheme against the manufactured solution
+    u = sin^4(pi t / Tg) sin^p(pi z / X) sin^p(pi x / X) of  u_tt + sigma(x) u_t = c(x)^2 (lap u + S)  -- the
+    continuous equation the damped leapfrog step A (2u - B u_prev + q) discretises (sigma = 2 d / dt); sigma is the
+    quadratic ramp over a quarter of the box, where u is 1e-2 .. 1e-1 of its peak."""
+    X, Tg = _MMS_X, _MMS_TG
+    h = X / (n - 1)
+    npml = (n - 1) // 4
+    nt = int(round(_MMS_TEND / dt))
+    dt = _MMS_TEND / nt
+    x, c = _mms_medium(n)
+    prof = fo.damping_profiles((n, n), npml, sigma_max, dt)
+    sig = (prof[0][:, None] + prof[1][None, :]) * 2.0 / dt
+    f0, _, f2 = _sink(np.pi * x / X, power)
+    f2 = f2 * (np.pi / X) ** 2
+    phi = f0[:, None] * f0[None, :]
+    lap = f2[:, None] * f0[None, :] + f0[:, None] * f2[None, :]
+    t = np.arange(nt) * dt
+    g, g1, g2 = _sink(np.pi * t / Tg, 4)
+    g1, g2 = g1 * np.pi / Tg, g2 * (np.pi / Tg) ** 2
+    S = (g2[:, None] * phi.ravel() + g1[:, None] * (sig * phi).ravel()) / c.ravel() ** 2 - g[:, None] * lap.ravel()
+    src, rec, st = _mms_points(n)
+    d = prop(c, h, dt, order, npml, sigma_max=sigma_max).forward(src, S * h ** 2, rec, save=False)
+    ex = _sink(np.pi * (t + dt) / Tg, 4)[0][:, None] * phi[::st, ::st].ravel()[None]
+    return float(np.linalg.norm(d - ex) / np.linalg.norm(ex))
+
+
+def test_manufactured_solution_heterogeneous_medium_with_sponge_second_order_in_time():
+    """dt ~ h refinement, O(8): the error falls 4x per level (second order in time; the space error is far below) and
+    ends below 1e-5 -- variable c and the damped update agree with an independent exact solution."""
+    dt0 = 0.5 * fo.cfl_dt(2640.0, _MMS_X / 40, 2, 8)
+    e = [_mms_sponge_error(n, 8, dt0 * 40.0 / (n - 1), power=6) for n in (41, 81, 161)]
+    assert 3.6 < e[0] / e[1] < 4.4 and 3.6 < e[1] / e[2] < 4.4, e
+    assert e[2] < 1e-5 and e[0] < 2e-4, e
+    assert abs(_mms_sponge_error(41, 8, dt0, power=6, prop=fo.Propagator) - e[0]) < 1e-9 * e[0]  # NumPy form too
+
+
+@pytest.mark.parametrize("order,ratio", [(2, 4.0), (4, 16.0)])
+def test_manufactured_solution_space_orders(order, ratio):
+    """Fixed tiny dt (time error ~1e-7): halving h divides the error by 2^order for O(2) and O(4) ..."""
+    e = [_mms_sponge_error(n, order, 2.5e-5) for n in (21, 41, 81)]
+    assert 0.85 * ratio < e[0] / e[1] < 1.15 * ratio and 0.85 * ratio < e[1] / e[2] < 1.15 * ratio, e
+
+
+def test_manufactured_solution_space_order_eight():
+    """... and by more than 2^7 for O(8) (191 measured: 3.3e-5 -> 1.7e-7, then the time error's floor)."""
+    e = [_mms_sponge_error(n, 8, 2.5e-5) for n in (21, 41)]
+    assert e[0] / e[1] > 128.0 and e[1] < 1e-6, e
+
+
+def _mms_cpml_error(n, dt, alpha_max, order=8, sigma_max=150.0, power=8, prop=CPropagator):
+    """The same manufactured u on the same medium with the CONVOLUTIONAL PML.  The recursions psi <- b psi + a D u,
+    zeta <- b zeta + a (E u + D psi) with b = exp(-(sigma + alpha) dt), a = sigma / (sigma + alpha) (b - 1) are the
+    exponential integrators of
+        psi_t = -lam psi - sigma u_x,   zeta_t = -lam zeta - sigma (u_xx + psi_x),   lam = sigma + alpha
+    (forcing held at its newest value over a step: first order in dt), and the field obeys
+        u_tt = c^2 (lap u + sum_d (d_d psi_d + zeta_d) + S).
+    For u = g(t) phi(x) the memory variables are convolutions of g with exp(-lam t): psi = -sigma phi_x G,
+    zeta = -sigma (phi_xx G - (sigma phi_x)_x H - sigma phi_x lam_x K) with G' = -lam G + g, H' = -lam H + G,
+    Gl = dG/dlam (Gl' = -lam Gl - G), K' = -lam K + Gl -- four scalar linear ODEs per distinct lam (one per border
+    node of an axis), integrated here to 1e-12 by an 8th-order Runge-Kutta: independent of the finite-difference
+    scheme.  S then follows in closed form."""
+    from scipy.integrate import solve_ivp
+    X, Tg = _MMS_X, _MMS_TG
+    h = X / (n - 1)
+    npml = (n - 1) // 4
+    L = npml * h
+    nt = int(round(_MMS_TEND / dt))
+    dt = _MMS_TEND / nt
+    x, c = _mms_medium(n)
+    xi = np.maximum(0.0, np.maximum(L - x, x - (X - L))) / L           # dist / npml as a function of x
+    sgn = np.where(x < L, -1.0, np.where(x > X - L, 1.0, 0.0))          # L d(xi)/dx
+    sig, dsig = sigma_max * xi ** 2, 2.0 * sigma_max * xi * sgn / L
+    lam, dlam = sig + alpha_max * (1.0 - xi), dsig - alpha_max * sgn / L
+    t = np.arange(nt) * dt
+    ker, cache = np.zeros((4, nt, n)), {}
+    for i in np.nonzero(xi > 0)[0]:
+        key = round(float(lam[i]), 9)
+        if key not in cache:
+            li = float(lam[i])
+            cache[key] = solve_ivp(lambda tt, y: [-li * y[0] + np.sin(np.pi * tt / Tg) ** 4, -li * y[1] + y[0],
+                                                  -li * y[2] - y[0], -li * y[3] + y[2]],
+                                   (0.0, _MMS_TEND), [0.0] * 4, method="DOP853", rtol=1e-12, atol=1e-16, t_eval=t).y
+        ker[:, :, i] = cache[key]
+    G, H, Gl, K = ker
+    f0, f1, f2 = _sink(np.pi * x / X, power)
+    f1, f2 = f1 * np.pi / X, f2 * (np.pi / X) ** 2
+    sf1, dsf1 = sig * f1, dsig * f1 + sig * f2
+    # one axis' d psi / dx + zeta as a function of (t, its coordinate), for a unit transverse factor
+    term = (-(dsf1[None] * G) - (sf1 * dlam)[None] * Gl) - sig[None] * (f2[None] * G - dsf1[None] * H - (sf1 * dlam)[None] * K)
+    g, _, g2 = _sink(np.pi * t / Tg, 4)
+    g2 = g2 * (np.pi / Tg) ** 2
+    phi = f0[:, None] * f0[None, :]
+    lap = f2[:, None] * f0[None, :] + f0[:, None] * f2[None, :]
+    S = (g2[:, None, None] * phi[None] / c[None] ** 2 - g[:, None, None] * lap[None]
+         - term[:, :, None] * f0[None, None, :] - f0[None, :, None] * term[:, None, :])
+    src, rec, st = _mms_points(n)
+    p = prop(c, h, dt, order, npml, sigma_max=sigma_max, abc="cpml", pml_alpha_max=alpha_max)
+    d = p.forward(src, S.reshape(nt, -1) * h ** 2, rec, save=False)
+    ex = _sink(np.pi * (t + dt) / Tg, 4)[0][:, None] * phi[::st, ::st].ravel()[None]
+    return float(np.linalg.norm(d - ex) / np.linalg.norm(ex))
+
+
+@pytest.mark.parametrize("alpha_max,last", [(60.0, 1e-4), (0.0, 3e-4)])
+def test_manufactured_solution_heterogeneous_medium_with_cpml(alpha_max, last):
+    """h -> h / 2 with dt -> dt / 4: the error falls 4x per level -- second order in h (the quadratic sigma ramp is
+    only C^1 at the border's inner edge, which caps the space order there) plus first order in dt (the recursive
+    convolution) -- and ends at 6.3e-5 (alpha_max = 60 / s; 1.8e-4 at alpha_max = 0): the CPML's a, b coefficients,
+    the two memory variables and their coupling into q converge to the continuous PML system on a variable medium."""
+    e = [_mms_cpml_error(n, dt, alpha_max) for n, dt in ((41, 1.6e-3), (81, 4e-4), (161, 1e-4))]
+    assert 3.4 < e[0] / e[1] < 4.8 and 3.4 < e[1] / e[2] < 4.8, e
+    assert e[2] < last, e
+    e_np = _mms_cpml_error(41, 1.6e-3, alpha_max, prop=fo.Propagator)
+    assert abs(e_np - e[0]) < 1e-9 * e[0]
+
+
+# ---------------------------------------------------------------------------
 # second absorbing boundary: convolutional PML (abc="cpml")
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,order", CASES)

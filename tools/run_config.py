@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"], help="absorbing border (fwi_config.abc)")
     ap.add_argument("--image-stride", type=int, default=1,
                     help="imaging condition every S-th step (fwi_config.image_stride)")
+    ap.add_argument("--checkpoint", default="", help="optimiser state file, rewritten after every iteration (rank 0 only)")
+    ap.add_argument("--resume", default="", help="continue from such a state file (every rank reads it)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -69,16 +71,17 @@ def main():
         return sh.misfit_and_gradient(pool, m, shots, ex)
 
     m0 = w.c_init.astype(np.float32)
+    ckpt = a.checkpoint if (a.checkpoint and rank == 0) else None  # every rank holds the same state: one writer
     bounds = (0.5 * float(w.c.min()), 1.5 * float(w.c.max()))
     if a.iters > 0 and not a.host_lbfgs:
         def fg_dev(xs, gs):
             evals[0] += 1
             return sh.misfit_and_gradient_device(pool, xs, gs, shots, ex)
         _, _, log = lbfgs_device(e, fg_dev, m0, maxiter=a.iters, history=5, first_step=0.02 * float(m0.max()),
-                                 bounds=bounds)
+                                 bounds=bounds, checkpoint=ckpt, resume=a.resume or None)
     elif a.iters > 0:
         _, _, log = lbfgs(fg, m0, maxiter=a.iters, history=5, first_step=0.02 * float(m0.max()),
-                          bounds=bounds, dot=e.dot)
+                          bounds=bounds, dot=e.dot, checkpoint=ckpt, resume=a.resume or None)
     else:
         J, g = fg(m0)
         log = [{"iter": 0, "f": J, "gnorm": float(np.sqrt(e.dot(g, g)))}]
