@@ -139,10 +139,11 @@ def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, ex
         if ex is not None and grad:
             e.allreduce_gradient()  # the shot loop's one exchange: sum of the per-rank gradients
         e.synchronize()
+        # (the collective alone: taken BEFORE the control-plane barrier that closes the timed region)
+        allreduce_ms = 1e3 * (time.perf_counter() - t1) if (ex is not None and grad) else None
         if barrier:
             barrier()
         el = t_shots + (time.perf_counter() - t1)
-        allreduce_ms = 1e3 * (time.perf_counter() - t1) if (ex is not None and grad) else None
         if grad and ex is not None:
             e.gradient_vec(0, "slowness2")
             gg_after = e.vec_dot(0, 0)
@@ -151,6 +152,15 @@ def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, ex
             check = {"g_dot_g_before_sum": gg_before, "g_dot_g_after_sum": gg_after, "ratio": ratio,
                      "expected_ratio": float(nr * nr), "ok": bool(abs(ratio - nr * nr) <= 1e-4 * nr * nr),
                      "note": "every rank runs the same shots, so the all-reduced accumulator is N x the local one"}
+            # A wrong or skipped RCCL sum must not exit 0 with a headline figure: the ranks agree on the
+            # outcome (the minimum of their verdicts, over RCCL itself) and ALL of them end non-zero.  At N = 1 the
+            # expected ratio is 1 whether or not the all-reduce ran -- only N > 1 discriminates, and no N > 1 run has
+            # been possible on the one-GPU boxes this was built on.
+            any_bad = e.allreduce_f64([0.0 if check["ok"] else 1.0], op="max")[0] > 0.0
+            if any_bad:
+                print("bench.py: gradient all-reduce check FAILED on %s: g.g after / before the sum = %r, expected %d"
+                      % ("this rank" if not check["ok"] else "another rank", ratio, nr * nr), file=sys.stderr)
+                raise SystemExit(3)
         if max_over_ranks:
             el = max_over_ranks(e, el)
         sweeps = 2 if grad else 1

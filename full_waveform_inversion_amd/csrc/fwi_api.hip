@@ -70,8 +70,9 @@ struct fwi_ctx {
     bool cpml = false;
     bool xpml = false;  // 3-D fp32 stream contexts: the x border's recursion runs inside the step kernel
     int pml_lines = 0;  // axes (z = 1, y = 2) whose border runs as one line launch per step (pml_line_axes)
-    bool zpml_fwd = false, zpml_rev = false;  // ... and the z border's (forward / adjoint sweeps)
-    std::vector<double> pml_za, pml_zb;       // host copies of the z axis' CPML coefficients
+    // ... whose term T_d the line launch hands to the step kernel: arrays compact over the axis' shell (StepArgs::pml_tz /
+    // pml_ty; scratch within one time step, so one pair serves every sweep of the context)
+    void *pml_tz = nullptr, *pml_ty = nullptr;
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
@@ -298,8 +299,7 @@ struct Impl {
         a.npml = ctx->cfg.npml;
         a.dz_scale = a.damp ? (T)(0.5 * ctx->cfg.dt * ctx->cfg.sigma_max /
                                   ((double)ctx->cfg.npml * ctx->cfg.npml)) : T(0);
-        a.zp_on = 0;
-        a.zp_psi = a.zp_zeta = nullptr;
+        a.pml_tz = a.pml_ty = nullptr;
         a.xp_mode = 0;
         a.xp_partial = 0;
         a.xp_psi = a.xp_zeta = nullptr;
@@ -370,6 +370,8 @@ struct Impl {
             p.dk1[k] = (T)(dc[k - 1] * h / co[1]);
         }
         p.npml = ctx->cfg.npml;
+        p.tz = (T *)ctx->pml_tz;
+        p.ty = (T *)ctx->pml_ty;
         return p;
     }
 
@@ -949,28 +951,23 @@ struct Impl {
                         a.xp_dk[k] = p.dk[k];
                         a.xp_dk1[k] = p.dk1[k];
                     }
-                    if (dn < 0 ? ctx->zpml_rev : ctx->zpml_fwd) {  // ... and the z border's on the z march
-                        axes = 2;
-                        a.zp_on = 1;
-                        a.zp_psi = p.psi[0];
-                        a.zp_zeta = p.zeta[0];
-                        for (int d = 1; d <= ctx->cfg.npml && d <= 64; ++d) {  // plane npml - d is d cells in
-                            a.zp_a[d - 1] = (T)ctx->pml_za[ctx->cfg.npml - d];
-                            a.zp_b[d - 1] = (T)ctx->pml_zb[ctx->cfg.npml - d];
-                        }
-                    }
                 }
-                // z / y borders the step kernel does not carry: one line launch per axis after it (all three phases;
-                // fwi_pml.hip, pml_line), the slab phases for whatever is left
+                // z / y borders: ONE line launch for both BEFORE the step (all three phases of the recursion; fwi_pml.hip,
+                // pml_line_t) hands their term to the step kernel, which adds it inside q; the slab phases around the step
+                // kernel take whatever is left (the x border of contexts whose lanes cannot carry it, grids without lines)
                 const int lines = axes & ctx->pml_lines;
                 axes &= ~lines;
+                if (lines) {
+                    HIPCHK(ctx, launch_pml_lines<T>(g, p, dn < 0, ctx->stream, lines));
+                    a.pml_tz = p.tz;
+                    a.pml_ty = p.ty;
+                }
                 if (axes) {
                     HIPCHK(ctx, launch_pml<T>(g, p, 1, dn < 0, ctx->stream, axes));
                     HIPCHK(ctx, launch_pml<T>(g, p, 2, dn < 0, ctx->stream, axes));
                 }
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
                 if (axes) HIPCHK(ctx, launch_pml<T>(g, p, 3, dn < 0, ctx->stream, axes));  // their term joins u' (and q)
-                if (lines) HIPCHK(ctx, launch_pml_lines<T>(g, p, dn < 0, ctx->stream, lines));
             } else {
                 HIPCHK(ctx, launch_step<T>(ctx->kernel, g, a, ctx->tune, ctx->stream));
             }
@@ -1477,10 +1474,6 @@ int create_impl(fwi_ctx *ctx) {
                 pb[i] = std::exp(-(sig + alp) * c.dt);
                 pa[i] = sig > 0.0 ? sig / (sig + alp) * (pb[i] - 1.0) : 0.0;
             }
-            if (d == 0) {
-                ctx->pml_za = pa;
-                ctx->pml_zb = pb;
-            }
             int rc2;
             if (c.dtype == FWI_F32) {
                 if ((rc2 = upload_vec<float>(ctx, ctx->pml_a[d], pa)) || (rc2 = upload_vec<float>(ctx, ctx->pml_b[d], pb)))
@@ -1490,6 +1483,17 @@ int create_impl(fwi_ctx *ctx) {
                     return rc2;
             }
         }
+    }
+    if (ctx->cpml && ctx->pml_lines == 3) {
+        // the handed-over border terms: (shell rows of z, ny, cx) and (nz + 1, shell rows of y, cx) -- one plane more than
+        // the grid, the stream kernel's prefetch runs one plane past the end.  Zeroed once: rows off a thread's shell
+        // re-read the first vectors of the arrays and discard them, which must not be NaNs of an earlier allocation.
+        const size_t bz = (size_t)pml_shell_rows(g.nz, c.npml, g.r) * g.ny * g.cx * es;
+        const size_t by = (size_t)(g.nz + 1) * pml_shell_rows(g.ny, c.npml, g.r) * g.cx * es;
+        HIPCHK(ctx, hipMalloc(&ctx->pml_tz, bz));
+        HIPCHK(ctx, hipMalloc(&ctx->pml_ty, by));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_tz, 0, bz, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_ty, 0, by, ctx->stream));
     }
     int rc;
     if (c.dtype == FWI_F32) {
@@ -1559,9 +1563,9 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->reserved0 != 0) return bad("reserved0 must be 0");
     if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
     if (cfg->store_dtype == FWI_STORE_BF16 &&
-        (cfg->ndim != 3 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
+        (cfg->ndim != 3 || cfg->order != 8 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
          cfg->update_form != FWI_UPDATE_STANDARD || (cfg->abc == FWI_ABC_CPML && cfg->npml > 0)))
-        return bad("store_dtype bf16: 3-D fp32 stream kernel, standard update form, sponge border, no checkpointing");
+        return bad("store_dtype bf16: 3-D fp32 O(8) stream kernel, standard update form, sponge border, no checkpointing");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -1627,7 +1631,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // =1 is the tuning / comparison hook)
     if (cfg->ndim == 3 && cfg->dtype == FWI_F32 && ctx->kernel == K_STREAM && !ctx->inc && !ctx->cpml) {
         const char *pe = getenv("FWI_STREAM_PAIR");
-        ctx->pair3d = pe ? atoi(pe) != 0 : false;
+        ctx->pair3d = (pe ? atoi(pe) != 0 : false) && cfg->npml == 0;  // (the two-step kernel exists undamped only)
         if (ctx->pair3d) {
             pair3d_default_tuning(ctx->gd, &ctx->pair_zc, &ctx->pair_tw);
             if (const char *zc = getenv("FWI_PAIR_ZCHUNK")) {
@@ -1636,22 +1640,15 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
             }
         }
     }
-    ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && !getenv("FWI_NO_STREAM_XPML") &&
+    // CPML in 3-D: the z / y borders run as ONE line launch before every step, which hands their term to the step kernel
+    // (both axes or none); with it the 3-D fp32 O(8) stream kernel carries the x border's recursion in its own lanes.
+    // Whatever is left runs as slab phases around the step kernel.
+    if (ctx->cpml && cfg->ndim == 3) ctx->pml_lines = pml_line_axes(ctx->gd, cfg->npml);
+    ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && ctx->pml_lines == 3 && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
-    // The z border on the z march is opt-in (FWI_STREAM_ZPML=1) since the line launches exist: it saves the z line
-    // launch (~21 us at 256^3 / npml 16) but costs the step kernel more than that (58 -> 84 us: the border planes all
-    // fall to the first and last z chunk, whose workgroups then decide the launch): forward 106 against 99 us/step.
-    if (ctx->xpml && !ctx->inc && cfg->npml % 4 == 0 && cfg->npml <= 64 && getenv("FWI_STREAM_ZPML") && !getenv("FWI_NO_STREAM_ZPML")) {
-        ctx->zpml_fwd = stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, false);
-        // the adjoint's form (two rings, 22 planes of LDS per thread column, ~100 registers parked in AGPRs) is slower
-        // than the slab launches it replaces (256^3: step kernel 65 -> 125 us against 28 us of slabs): opt-in only
-        ctx->zpml_rev = getenv("FWI_STREAM_ZPML_REV") && stream_zpml_supported(ctx->gd, ctx->tune, cfg->npml, true);
-    }
-    if (ctx->cpml) ctx->pml_lines = pml_line_axes(ctx->gd, cfg->npml);
     if (getenv("FWI_DEBUG_PML"))
-        fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d z-in-kernel fwd=%d rev=%d line-axes=%d (ty %d zchunk %d)\n",
-                (int)ctx->cpml, (int)ctx->fused2d, (int)ctx->xpml, (int)ctx->zpml_fwd, (int)ctx->zpml_rev, ctx->pml_lines,
-                ctx->tune.ty, ctx->tune.zchunk);
+        fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d line-axes=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
+                (int)ctx->fused2d, (int)ctx->xpml, ctx->pml_lines, ctx->tune.ty, ctx->tune.zchunk);
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
@@ -1696,6 +1693,8 @@ void fwi_destroy(fwi_ctx *ctx) {
                         ctx->pml_zeta_fw[d], ctx->pml_spare_psi[d], ctx->pml_spare_zeta[d]})
             if (q) (void)hipFree(q);
     if (ctx->pml_snap) (void)hipFree(ctx->pml_snap);
+    for (void *q : {ctx->pml_tz, ctx->pml_ty})
+        if (q) (void)hipFree(q);
     if (ctx->fused_order) (void)hipFree(ctx->fused_order);
     for (fwi_ctx::SpreadSet *sp : {&ctx->src_sp, &ctx->rec_sp})
         for (void *q : {sp->pt_start, sp->owner, sp->weight})

@@ -63,12 +63,13 @@ struct StepArgs {
     T *xp_psi, *xp_zeta;
     const T *xp_a, *xp_b;
     T xp_dk[5], xp_dk1[5];
-    // ... and of the z border on the z march (zp_on; same direction and weights as xp_*): memory variables in the slab
-    // kernels' layout (2 npml, ny, cx), coefficients BY DISTANCE into the border (entry d - 1 for a plane d cells in;
-    // the two borders are mirror images), kept in the kernel arguments so that they are scalar loads
-    int zp_on;
-    T *zp_psi, *zp_zeta;
-    T zp_a[64], zp_b[64];
+    // Convolutional PML of the z / y border (3-D): its term T_d = D psi_d' + zeta_d' (adjoint: E alpha_d - D beta_d) is
+    // formed BEFORE the step by the line launch (fwi_pml.hip, pml_line_t: it depends on the newest field and the memory
+    // variables only) and handed over in arrays compact over the axis' SHELL -- the border and the r cells its term
+    // reaches: (shell rows of z, ny, cx) for z, (nz, shell rows of y, cx) for y; pml_shell_rows / pml_shell_index.  The
+    // step kernel adds them inside q = C (L u + sum_d T_d + ...): no second pass over u' (v', q), no re-read of C.
+    // nullptr = none.
+    const T *pml_tz, *pml_ty;
 
     // Point operations fused into the step kernels (all nullptr / 0 = none).
     // Injection into u_next (and q_out): entries sorted by workgroup tile,
@@ -113,6 +114,10 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32);
 template <typename T>
 hipError_t launch_step(int kernel, const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t,
                        hipStream_t s);
+// The 3-D stream kernel's dispatch for one dtype and stencil radius (fwi_stream3d.h); instantiated in
+// fwi_stream3d_*.hip, one translation unit per dtype / order group.
+template <typename T, int R>
+hipError_t launch_stream_r(const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t, hipStream_t s);
 
 // out[i] = u[pidx[i]] * scale
 template <typename T>
@@ -151,6 +156,17 @@ template <typename T>
 hipError_t launch_residual_l2(const T *syn, T *obs_inout, int64_t n, double *out, hipStream_t s);
 
 // ---- convolutional PML (fwi_pml.hip): slab kernels around the undamped step kernels ------------------------
+// The SHELL of an axis of n cells: its two borders and the r cells inward that their term reaches (the rows whose
+// update takes a CPML term of that axis).  When the two shells meet (n < 2 npml + 3 r, the line kernel's one-segment
+// case) the shell is the whole axis.  Rows are numbered low border first.
+__host__ __device__ inline int pml_shell_rows(int n, int npml, int r) { return n < 2 * npml + 3 * r ? n : 2 * (npml + r); }
+__host__ __device__ inline bool pml_in_shell(int j, int n, int npml, int r) {
+    return n < 2 * npml + 3 * r || j < npml + r || j >= n - npml - r;
+}
+__host__ __device__ inline int pml_shell_index(int j, int n, int npml, int r) {  // (of a row in the shell)
+    return (n < 2 * npml + 3 * r || j < npml + r) ? j : j - (n - 2 * (npml + r));
+}
+
 template <typename T>
 struct PmlArgs {
     const T *u_cur;   // the newest field (padded): u^n forward, mu^{j+2} in the adjoint sweep
@@ -164,21 +180,21 @@ struct PmlArgs {
     T dk[5];          // first-difference weights d_k / h, k = 1..r: D of a memory variable
     T dk1[5];         // d_k h / a_1: D of the field inside the memory-variable recursions (memory variables x h^2 / a_1)
     int npml;
+    T *tz, *ty;       // line form: where the z / y border's term goes (StepArgs::pml_tz / pml_ty), or nullptr
 };
 // phase 1, 2: advance the memory variables (before the step kernel); 3: add their term to u' (after it)
 // `axes`: bit d set = run axis d (z = 1, y = 2, x = 4); an axis the step kernel carries itself is left out
 template <typename T>
 hipError_t launch_pml(const GridDesc &g, const PmlArgs<T> &p, int phase, int reverse, hipStream_t s, int axes = 7);
-// Line form of the z / y border (3-D): ONE launch per axis after the step kernel does all three phases (a thread
-// marches its line through the border with the field and the new memory variables in register windows).
+// Line form of the z / y border (3-D): ONE launch for both axes BEFORE the step kernel advances the memory variables
+// and writes the border's term into PmlArgs::tz / ty (a thread marches its line through the border with the field and
+// the new memory variables in register windows); the step kernel adds the term inside q (StepArgs::pml_tz / pml_ty).
 // pml_line_axes: the axes (z = 1, y = 2) it takes for this grid -- the slab phases are then run without them.
 int pml_line_axes(const GridDesc &g, int npml);
 template <typename T>
 hipError_t launch_pml_lines(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes);
 // True when the 3-D stream kernel can carry the x border's recursion in its lanes (see step3d_stream, XP)
 bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool is_f32);
-// ... the z border's on its z march as well (ZP); `reverse`: the adjoint sweep (its rings need 4-row tiles)
-bool stream_zpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool reverse);
 
 // ---- 2-D temporal blocking (fwi_fused2d.hip): FUSED2D_STEPS time steps per launch ----------------
 constexpr int FUSED2D_STEPS = 4;   // time steps advanced per launch

@@ -12,17 +12,9 @@
 // which is algebraically the centred star but keeps fp32 round-off ~30x lower
 // over thousands of steps than the coefficient form (the rounded coefficients
 // of the latter do not sum to zero, which acts as a spurious mass term).
-#include "fwi_kernels.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <type_traits>
+#include "fwi_device.h"
 
 namespace fwi {
-
-static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     GridDesc g;
@@ -56,34 +48,6 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     g.cx = (int)round_up(nx, 4);
     g.npts = (int64_t)nz * g.ny * g.cx;
     return g;
-}
-
-// Source / residual injection into the points a workgroup has just written.  The host sorts a tile's entries by
-// node, so the entries of one node are consecutive: the thread of a run's FIRST entry adds the whole run, in entry
-// order, and issues ONE add per node -- duplicate nodes (two sources on one node) sum in a fixed order:
-// bit-reproducible.  A node belongs to exactly one tile, so no other workgroup touches it; the caller's barrier has
-// drained this workgroup's own stores of u'.
-template <typename T, bool INC, bool Q>
-__device__ __forceinline__ void inject_runs(const StepArgs<T> &a, int s0, int s1, int tid, int nth) {
-    for (int i = s0 + tid; i < s1; i += nth) {
-        // entry i's operands all at once (one level of loads, then the amplitude): the common run of 1 costs what
-        // the plain per-entry form did
-        const int run = a.inj_run[i];  // host-made: length of the node's run at its first entry, 0 at the others
-        const int64_t p = a.inj_pidx[i];
-        const T amp0 = a.inj_amp[a.inj_col[i]];
-        T su = a.inj_cu[i] * amp0, sq = Q ? a.inj_cq[i] * amp0 : T(0);
-        if (run == 0) continue;  // a later entry of its node's run: the first one's thread adds it
-        for (int j = i + 1; j < i + run; ++j) {
-            const T amp = a.inj_amp[a.inj_col[j]];
-            su += a.inj_cu[j] * amp;
-            if (Q) sq += a.inj_cq[j] * amp;
-        }
-        // ONE add per node and field: atomics only because they need no round trip (a plain read-modify-write would
-        // put an L2 latency at the very end of the kernel); with one add per address the result is order-free
-        atomicAdd(a.u_prev + p, su);
-        if (INC) atomicAdd(a.v + p, su);  // the source moves u' and v' alike
-        if (Q) atomicAdd(a.q_out + a.inj_cidx[i], sq);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -124,6 +88,12 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
             t = fma(T(-2 * NDIM), uc, t);
             lap = fma(a.ck[k], t, lap);
         }
+        if (NDIM == 3 && a.pml_tz) {  // the z / y border's CPML term, handed over by the line launch before this step
+            if (pml_in_shell(z, g.nz, a.npml, R))
+                lap += a.pml_tz[((int64_t)pml_shell_index(z, g.nz, a.npml, R) * g.ny + y) * g.cx + x];
+            if (pml_in_shell(y, g.ny, a.npml, R))
+                lap += a.pml_ty[((int64_t)z * pml_shell_rows(g.ny, a.npml, R) + pml_shell_index(y, g.ny, a.npml, R)) * g.cx + x];
+        }
         const T q = a.C[p] * lap;
         const T up = INC ? a.v[p] : a.u_prev[p];  // increment form: the operand is v^n = u^n - u^{n-1}
         T un;
@@ -159,726 +129,8 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
     }
 }
 
-// ---------------------------------------------------------------------------
-// STREAM kernel (3-D, fp32 and fp64): a workgroup of 64 x TY threads owns a
-// (64 VL) x TY (x, y) tile -- VL = 4 floats or 2 doubles per lane -- and marches
-// `zchunk` planes in z.  Each thread owns one 16-byte vector (VL consecutive x)
-// per plane: every global access is a coalesced 16 B/lane stream, a wave
-// covers 1 KiB of one row.
-//   z neighbours : register queue of 2r+2 vectors, the next plane fetched
-//                  straight into it one plane ahead; z loop unrolled by the
-//                  queue length so all indices are static (no rotation).
-//   y neighbours : the current plane's TY + 2r rows staged in LDS (double
-//                  buffered, so ONE barrier per plane); the 2r halo rows are
-//                  fetched r planes ahead (right behind the neighbouring tile
-//                  streaming them) by the waves themselves.
-//   x neighbours : the row's left/right vectors read back from the same LDS
-//                  row (lanes 0-3 / 60-63 add the 4 edge elements per side).
-// Algorithmic traffic 16 B/point in fp32 (u_cur, u_prev, C in; u_next out);
-// the halo re-reads ((TY+2r)/TY in y, (zchunk+2r)/zchunk in z) are L2 /
-// Infinity Cache traffic.  Blocks are renumbered so each XCD (private 4 MiB
-// L2) owns a contiguous slab of tiles and shares those halo rows on chip.
-// ---------------------------------------------------------------------------
-// 16-byte vector of the field type: float4 / double2.  One per lane = 1 KiB per wave-instruction.
-template <typename T> struct VecOf;
-template <> struct VecOf<float> {
-    static constexpr int VL = 4;
-    typedef float nt_t __attribute__((ext_vector_type(4)));
-};
-template <> struct VecOf<double> {
-    static constexpr int VL = 2;
-    typedef double nt_t __attribute__((ext_vector_type(2)));
-};
-template <typename T>
-struct alignas(16) vec {
-    T v[VecOf<T>::VL];
-};
-using f4 = vec<float>;
-
-template <typename T>
-__device__ __forceinline__ vec<T> ldv(const T *p) { return *reinterpret_cast<const vec<T> *>(p); }
-template <typename T>
-__device__ __forceinline__ void stv(T *p, const vec<T> &v) { *reinterpret_cast<vec<T> *>(p) = v; }
-
-// Streaming (non-temporal) forms for the once-per-step traffic of the imaging term q: it is
-// written once in the forward pass and read once in the adjoint pass, tens of GiB per shot, and
-// must not evict the wavefields from L2 / Infinity Cache.
-template <typename T>
-__device__ __forceinline__ vec<T> ldv_stream(const T *p) {
-    typedef typename VecOf<T>::nt_t nt_t;
-    const nt_t v = __builtin_nontemporal_load(reinterpret_cast<const nt_t *>(p));
-    vec<T> r;
-#pragma unroll
-    for (int j = 0; j < VecOf<T>::VL; ++j) r.v[j] = v[j];
-    return r;
-}
-template <typename T>
-__device__ __forceinline__ void stv_stream(T *p, const vec<T> &f) {
-    typedef typename VecOf<T>::nt_t nt_t;
-    nt_t v;
-#pragma unroll
-    for (int j = 0; j < VecOf<T>::VL; ++j) v[j] = f.v[j];
-    __builtin_nontemporal_store(v, reinterpret_cast<nt_t *>(p));
-}
-// Forward-term store in bf16 (fwi_config.store_dtype): 4 values = 8 bytes per lane, round to nearest even on the
-// way out, exact on the way in.  bf16 keeps fp32's exponent, so the term needs no scaling.  The conversion is the
-// plain cast (v_cvt_pk_bf16_f32): the integer-rounding form (u + 0x7fff + lsb) >> 16 turns some NaNs into 0 or
-// infinity (MI355X_MICROARCH.md, correctness boundaries), which would launder a blown-up forward run into a
-// finite-looking gradient; the cast keeps every NaN a NaN and rounds finite values identically.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void st_bf16x4_stream(void *base, int64_t elem, const vec<float> &q) {
-    u32x2 w;
-    w[0] = bf16_pack2(q.v[0], q.v[1]);
-    w[1] = bf16_pack2(q.v[2], q.v[3]);
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned short *>(base) + elem));
-}
-__device__ __forceinline__ vec<float> ld_bf16x4_stream(const void *base, int64_t elem) {
-    const u32x2 w = __builtin_nontemporal_load(
-        reinterpret_cast<const u32x2 *>(reinterpret_cast<const unsigned short *>(base) + elem));
-    vec<float> q;
-    q.v[0] = __uint_as_float(w[0] << 16);
-    q.v[1] = __uint_as_float(w[0] & 0xffff0000u);
-    q.v[2] = __uint_as_float(w[1] << 16);
-    q.v[3] = __uint_as_float(w[1] & 0xffff0000u);
-    return q;
-}
-template <typename T>
-__device__ __forceinline__ void st_q(T *base, int64_t elem, const vec<T> &q, bool) { stv_stream<T>(base + elem, q); }
-template <typename T>
-__device__ __forceinline__ vec<T> ld_q(const T *base, int64_t elem, bool) { return ldv_stream<T>(base + elem); }
-template <bool QB>
-__device__ __forceinline__ void st_qf(float *base, int64_t elem, const vec<float> &q) {
-    if (QB) st_bf16x4_stream(base, elem, q); else stv_stream<float>(base + elem, q);
-}
-template <bool QB>
-__device__ __forceinline__ vec<float> ld_qf(const float *base, int64_t elem) {
-    return QB ? ld_bf16x4_stream(base, elem) : ldv_stream<float>(base + elem);
-}
-template <bool QB>
-__device__ __forceinline__ void st_qf(double *base, int64_t elem, const vec<double> &q) { stv_stream<double>(base + elem, q); }
-template <bool QB>
-__device__ __forceinline__ vec<double> ld_qf(const double *base, int64_t elem) { return ldv_stream<double>(base + elem); }
-
-__device__ __forceinline__ f4 ld4(const float *p) { return ldv<float>(p); }
-__device__ __forceinline__ void st4(float *p, const f4 &v) { stv<float>(p, v); }
-__device__ __forceinline__ f4 ld4_stream(const float *p) { return ldv_stream<float>(p); }
-__device__ __forceinline__ void st4_stream(float *p, const f4 &v) { stv_stream<float>(p, v); }
-
-// 1 / a for a in [1, 2): hardware reciprocal (1 ulp) + one Newton step, ~0.5 ulp; replaces the
-// ~12-instruction IEEE division in the damping factor A = 1 / (1 + d).
-__device__ __forceinline__ float rcp_nr(float a) {
-    const float r = __builtin_amdgcn_rcpf(a);
-    return r * fmaf(-a, r, 2.f);
-}
-__device__ __forceinline__ double rcp_nr(double a) { return 1.0 / a; }
-
 constexpr int TILE_X = 256;                // 2-D tile kernel: floats per tile row = 64 lanes x float4
 constexpr int LROW4 = TILE_X / 4 + 2;      // its LDS row in float4: [left edge][64][right edge]
-
-// IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
-// read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
-// XP: the convolutional PML of the x border carried in the lanes (1 = forward recursion, 2 = its transpose): the
-// border cells of a row are the first / last npml / 4 lanes of the wave that owns it, psi' of the neighbouring cells
-// comes through __shfl_up / __shfl_down (the 2 r-wide dependence of the border recursion never leaves the wave),
-// D u and E_x u from the x window the stencil has in registers anyway.  The memory variables are read and written
-// once per step by the lanes that own them -- no slab launches for this axis, no second pass over u' and q.
-// ZP (with XP: the same direction): the z border's recursion rides on the z march.  The queue runs r planes further
-// ahead (planes z - r .. z + 2r), so psi' of plane z + r -- which needs u(z .. z + 2r) -- is formed r planes before the
-// update of plane z reads psi'(z - r .. z + r); those 2r + 1 planes of psi' wait in a per-thread LDS ring (no thread
-// reads another's slot: no barrier).  The adjoint recursion keeps a zt' = alpha / a ring over z - r .. z + 2r and a
-// beta = a pt' ring over z - r .. z + r.  All of it sits under one wave-uniform test of the plane index -- planes
-// further than 2r from a border pay nothing but two clamped loads -- and holds no global LOAD (the pipelined loop keeps
-// its counted vmcnt).  Chunk seams must stay 2r planes clear of the borders (stream_zpml_supported).
-template <typename T, int R, int TY, bool DAMP, bool SAVE_Q, int IMAGE, bool FULL, int PF, bool INC = false,
-          bool QB = false, int XPM = 0, bool ZP = false>
-__global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc g, int zchunk,
-                                                         int nxt, int nyt, int nblk, int tw) {
-    // XPM 1 / 2: the x border in the lanes, forward / adjoint; 3 / 4: the same for a border whose width is not a
-    // multiple of the lane vector (npml = 10, 14, ...): the one lane per side that straddles the border's inner edge
-    // stores its memory variables cell by cell (the slab row holds the other side's cells right behind)
-    constexpr int XP = XPM == 0 ? 0 : ((XPM - 1) & 1) + 1;
-    constexpr bool XMASK = XPM > 2;
-    constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
-    constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
-    constexpr int LROWS = TY + 2 * R + 1;
-    constexpr int VL = VecOf<T>::VL;       // elements per lane: float4 / double2
-    constexpr int HV = HALO / VL;          // vectors per x-halo side (1 / 2)
-    constexpr int TX = 64 * VL;            // tile row in elements (256 / 128)
-    constexpr int LROWV = 64 + 2 * HV;     // LDS row in vectors: [left edge][64 lanes][right edge]
-    using V = vec<T>;
-    __shared__ V lds[2][LROWS][LROWV];
-
-    const int lane = threadIdx.x, ty = threadIdx.y;
-    int bid = blockIdx.x;
-    if (bid >= nblk) {
-        // Receiver sampling rides along as extra workgroups: u_cur is read-only in this
-        // launch and already holds the previous step's field including its injection.
-        for (int i = (bid - nblk) * (64 * TY) + ty * 64 + lane; i < a.nrec; i += (gridDim.x - nblk) * 64 * TY)
-            a.rec_out[i] = a.u_cur[a.rec_pidx[i]] * a.rec_scale;
-        return;
-    }
-    if (zchunk > 0) {  // XCD-contiguous slabs: XCD x runs blocks x, x + 8, ... -> give it one contiguous range
-        const int x = bid & 7, q = nblk >> 3, r = nblk & 7;  // the first r XCDs hold q + 1 blocks
-        bid = x * q + min(x, r) + (bid >> 3);
-    }
-    zchunk = abs(zchunk);  // (a negative zchunk is the tuning hook that switches the renumbering off)
-    const int bx = bid % nxt;
-    const int t2 = bid / nxt;
-    const int by = t2 % nyt, bz = t2 / nyt;
-    // x tiles are `tw` columns wide (a multiple of VL, <= TX): the host splits nx into equal tiles, so
-    // a grid of 384 columns runs as 2 x 192 (48 lanes each) instead of 256 + 128 -- same idle lanes,
-    // but every workgroup then moves the same bytes and none is the straggler (384^3: 224 -> 269
-    // Gpts/s).  FULL: tw == TX.
-    const int twid = FULL ? TX : tw;
-    const int x0 = bx * twid + VL * lane;
-    const int y0 = by * TY, y = y0 + ty;
-    const int z0 = bz * zchunk;
-    const int z1 = min(g.nz, z0 + zchunk);
-    const bool act = FULL || ((VL * lane < twid) && (x0 < g.nx) && (y < g.ny));
-    const int64_t sz = g.sz, sy = g.sy;
-    // Lanes that own no points store nothing, but the loop is branch-free, so they load.  The first
-    // HALO columns right of the tile are the x halo of its last lanes: those lanes load the real field
-    // there (which makes the right-edge scalars below redundant unless tw == TX).  Lanes further right
-    // repeat the last halo vector, and lanes right of the GRID all read the one all-zero vector just
-    // behind the row's last data vector (pad, never written): the same cache lines as real data instead
-    // of a stream of pad lines, and exactly the zeros the neighbouring lanes' x stencil must see.
-    const int xa = FULL ? x0 : min(min(x0, bx * twid + twid + HALO - VL), ((g.nx - 1) / VL + 1) * VL);
-
-    // Addressing: wave-uniform 64-bit plane base (SGPRs) + per-thread 32-bit
-    // in-plane offset (one VGPR shared by u_cur, u_prev and C, which have the
-    // same padded layout).
-    const unsigned poff = (unsigned)(g.off0 + (int64_t)y * sy + xa);  // (z = 0, y, x0)
-    const unsigned coff = (unsigned)((int64_t)y * g.cx + x0);         // compact, z = 0
-    const int64_t cplane = (int64_t)g.ny * g.cx;
-
-    // The loop below is free of divergent branches so that hipcc can count its
-    // s_waitcnt vmcnt(N) exactly and keep the prefetches in flight across
-    // iterations: slots with nothing to fetch re-load their own address and
-    // write to the TRASH row instead of branching.
-    // Halo rows: hr in [0, 2R), below (hr < R) or above the tile.
-    unsigned hoff[NH];
-    int hrow[NH];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        const int hr = ty + i * TY;
-        const bool valid = hr < 2 * R;
-        const int yh = !valid ? y : (hr < R) ? y0 - R + hr : y0 + TY + (hr - R);
-        hrow[i] = !valid ? TRASH : (hr < R) ? hr : TY + hr;
-        hoff[i] = (unsigned)(g.off0 + (int64_t)yh * sy + xa);
-    }
-    // x edges: lanes 0-3 fetch the 4 elements left of the tile row, lanes 60-63
-    // the 4 elements right of it (one scalar load each).
-    const unsigned rowoff = (unsigned)(g.off0 + (int64_t)y * sy + bx * twid);
-    // (idle lanes 4..59 all repeat lane 3's address: one cache line per wave instead of the eight their own
-    // vectors span -- those re-loads were a quarter of the kernel's L2 requests)
-    const unsigned eoff = (lane < 4) ? rowoff - 4 + lane : (lane >= 60) ? rowoff + TX + (lane - 60) : rowoff - 1;
-    const int erow = (lane < 4 || lane >= 60) ? R + ty : TRASH;
-    // idle lanes write consecutive words of the trash row (a 16 B stride would be a 4-way bank conflict)
-    const int ecol = (lane < 4) ? lane : (lane >= 60) ? (HV + 64) * VL + (lane - 60) : lane;
-
-    // loop-invariant xy part of the damping
-    V Axy, Bxy, dxy;
-    if (DAMP) {
-        const T dyv = (y < g.ny) ? a.dy[y] : T(0);
-#pragma unroll
-        for (int j = 0; j < VL; ++j) {
-            const T d = dyv + ((x0 + j < g.nx) ? a.dx[x0 + j] : T(0));
-            dxy.v[j] = d;
-            Bxy.v[j] = T(1) - d;
-            Axy.v[j] = rcp_nr(T(1) + d);
-        }
-    }
-
-    // x-border CPML in the lanes: a(x), b(x) of this lane's cells (0 off the border, so that psi and zeta vanish
-    // there whatever was loaded), the lane's offset in a row of the memory-variable arrays (nz, ny, 2 npml)
-    V xca, xcb;
-    unsigned xld = 0;
-    bool xin = false;
-    unsigned xcells = 0;  // (XMASK) which of the lane's cells are border cells
-    int64_t xplane = 0;
-    if constexpr (XP != 0) {
-        const int nsl = 2 * a.npml;
-        xplane = (int64_t)g.ny * nsl;
-        bool in = false;
-#pragma unroll
-        for (int j = 0; j < VL; ++j) {
-            const int x = x0 + j;
-            const bool b = x < g.nx && (x < a.npml || x >= g.nx - a.npml);
-            xca.v[j] = b ? a.xp_a[x] : T(0);
-            xcb.v[j] = b ? a.xp_b[x] : T(0);
-            in |= b;
-            xcells |= b ? 1u << j : 0u;
-        }
-        xin = act && in;  // (XMASK off: npml and nx are multiples of VL, a lane's cells are all in the border or all out)
-        const int jx = x0 < a.npml ? x0 : x0 - (g.nx - nsl);
-        xld = (unsigned)((int64_t)min(y, g.ny - 1) * nsl + (xin ? jx : 0));  // lanes off the border re-read column 0
-    }
-
-    // z register queue: plane p lives in slot (p - z0 + R) % NQ.  PF planes are fetched ahead of
-    // use straight into the queue; the pointwise operands (u_prev, C), halo rows and edge pieces
-    // sit in rings of PF + 1 slots.  NQ is a multiple of PF + 1 and the z loop is unrolled NQ
-    // times, so every queue / ring index below is a compile-time constant: no register
-    // rotations, and hipcc keeps the prefetches of planes z+1 .. z+PF in flight while plane z is
-    // computed (exact vmcnt counts).  PF >= 2 matters at one wave per SIMD: one plane takes
-    // ~0.6 us, less than a loaded L2-miss round trip.
-    // The y-halo rows are fetched R planes ahead (ring of R + 1 slots, which divides NQ): that is
-    // (almost) when the neighbouring tile, whose interior rows they are, streams the same plane
-    // into its own z queue, so the second request hits in the XCD's L2 instead of going back to
-    // HBM ~4 planes later (measured at 512^3: traffic 1.235x algorithmic before).
-    constexpr int NR = PF + 1;
-    constexpr int QE = ZP ? R : 0;  // planes the queue runs further ahead for the z border's recursion
-    constexpr int NQ = (2 * R + 1 + QE + PF + NR - 1) / NR * NR;
-    constexpr int HPF = (NQ % (R + 1) == 0) ? R : PF;  // halo prefetch distance
-    constexpr int NRH = HPF + 1;
-    V zq[NQ];
-    // (ZP: the last prefetches would run one plane past the zero planes behind the grid: clamped onto the last one)
-    const int zlast = g.nz + HALO + LOOKAHEAD - 1;
-#pragma unroll
-    for (int k = 0; k < 2 * R + QE + PF; ++k)
-        zq[k] = ldv<T>(a.u_cur + (int64_t)(ZP ? min(z0 - R + k, zlast) : z0 - R + k) * sz + poff);
-    V up[NR], Cc[NR], halo[NRH][NH];
-    V xps[XP ? NR : 1], xzt[XP ? NR : 1];  // psi / zeta (adjoint: pt / zt) of the x border, fetched like up / Cc
-    V zps[ZP ? NR : 1], zzt[ZP ? NR : 1];  // ... of the z border: psi(z + r) / zeta(z); adjoint pt(z + r) / zt(z + 2r)
-    T edge[NR];
-    // increment form: the pointwise operand is v^n (its own padded field) instead of u^{n-1}
-    const T *const pw = INC ? a.v : a.u_prev;
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-        const int64_t o = (int64_t)(z0 + p) * sz;
-        up[p] = ldv<T>(pw + o + poff);
-        Cc[p] = ldv<T>(a.C + o + poff);
-        edge[p] = a.u_cur[o + eoff];
-        if constexpr (XP != 0) {
-            xps[p] = ldv<T>(a.xp_psi + (int64_t)min(z0 + p, g.nz - 1) * xplane + xld);
-            xzt[p] = ldv<T>(a.xp_zeta + (int64_t)min(z0 + p, g.nz - 1) * xplane + xld);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < HPF; ++p) {
-        const int64_t o = (int64_t)(z0 + p) * sz;
-#pragma unroll
-        for (int i = 0; i < NH; ++i) halo[p][i] = ldv<T>(a.u_cur + o + hoff[i]);
-    }
-
-
-    // ---- z border in the march (ZP) ----------------------------------------------------------------------------
-    // rings: forward psi' over planes z - r .. z + r; adjoint alpha = a zt' over z - r .. z + 2r, beta = a pt' over
-    // z - r .. z + r.  Slot of plane p = (p - z0 + r) mod ring length; a thread touches only [.][ty][lane].
-    constexpr int NSA = ZP ? (XP == 2 ? 3 * R + 1 : 2 * R + 1) : 1, NSB = (ZP && XP == 2) ? 2 * R + 1 : 1;
-    __shared__ V zra[NSA][ZP ? TY : 1][ZP ? 64 : 1];
-    __shared__ V zrb[NSB][(ZP && XP == 2) ? TY : 1][(ZP && XP == 2) ? 64 : 1];
-    const unsigned zco = act ? coff : 0u;  // this thread's offset in a plane of the z memory variables (compact)
-    // coefficient of plane p by its distance into the border (kernel arguments: scalar loads), 0 off the border
-    auto zdist = [&](int p) { return (p >= 0 && p < g.nz) ? max(0, max(a.npml - p, p - (g.nz - 1 - a.npml))) : 0; };
-    auto zslab = [&](int p) { return p < a.npml ? max(p, 0) : (p >= g.nz - a.npml ? min(p, g.nz - 1) - (g.nz - 2 * a.npml) : 0); };
-    if constexpr (ZP) {
-        const V zero = {};
-        const bool lo_near = z0 < a.npml + 2 * R;  // (chunk seams are 2r clear of the borders: only chunk 0 starts inside one)
-        if (XP == 1) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) zra[(unsigned)r % NSA][ty][lane] = zero;  // planes z0 - r .. z0 - 1
-            // psi' of planes z0 .. z0 + r - 1 (the loop forms psi'(z + r) at plane z)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int p = z0 + r, d = zdist(p);
-                V v = zero;
-                if (lo_near && d > 0) {
-                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
-                    const V old = ldv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T du = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) du = fma(a.xp_dk1[k], zq[r + R + k].v[j] - zq[r + R - k].v[j], du);
-                        v.v[j] = fma(bv, old.v[j], av * du);
-                    }
-                    if (act) stv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco, v);
-                }
-                zra[(unsigned)(r + R) % NSA][ty][lane] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                zps[i] = ldv<T>(a.zp_psi + (int64_t)zslab(z0 + R + i) * cplane + zco);
-                zzt[i] = ldv<T>(a.zp_zeta + (int64_t)zslab(z0 + i) * cplane + zco);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                zra[(unsigned)r % NSA][ty][lane] = zero;
-                zrb[(unsigned)r % NSB][ty][lane] = zero;
-            }
-            // alpha of planes z0 .. z0 + 2r - 1, then beta of planes z0 .. z0 + r - 1
-#pragma unroll
-            for (int r = 0; r < 2 * R; ++r) {
-                const int p = z0 + r, d = zdist(p);
-                V v = zero;
-                if (lo_near && d > 0) {
-                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
-                    V zt = ldv<T>(a.zp_zeta + (int64_t)zslab(p) * cplane + zco);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        zt.v[j] = fma(bv, zt.v[j], zq[r + R].v[j]);
-                        v.v[j] = av * zt.v[j];
-                    }
-                    if (act) stv<T>(a.zp_zeta + (int64_t)zslab(p) * cplane + zco, zt);
-                }
-                zra[(unsigned)(r + R) % NSA][ty][lane] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int p = z0 + r, d = zdist(p);
-                V v = zero;
-                if (lo_near && d > 0) {
-                    const T av = a.zp_a[d - 1], bv = a.zp_b[d - 1];
-                    V pt = ldv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T dw = T(0);  // D (mu + alpha)
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            const V ap = zra[(unsigned)(r + R + k) % NSA][ty][lane], am = zra[(unsigned)(r + R - k) % NSA][ty][lane];
-                            dw = fma(a.xp_dk1[k], (zq[r + R + k].v[j] + ap.v[j]) - (zq[r + R - k].v[j] + am.v[j]), dw);
-                        }
-                        pt.v[j] = bv * pt.v[j] - dw;
-                        v.v[j] = av * pt.v[j];
-                    }
-                    if (act) stv<T>(a.zp_psi + (int64_t)zslab(p) * cplane + zco, pt);
-                }
-                zrb[(unsigned)(r + R) % NSB][ty][lane] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                zps[i] = ldv<T>(a.zp_psi + (int64_t)zslab(z0 + R + i) * cplane + zco);
-                zzt[i] = ldv<T>(a.zp_zeta + (int64_t)zslab(z0 + 2 * R + i) * cplane + zco);
-            }
-        }
-    }
-
-    for (int zb = z0; zb < z1; zb += NQ) {
-#pragma unroll
-        for (int ph = 0; ph < NQ; ++ph) {
-            const int z = zb + ph;
-            if (z >= z1) break;
-            const int cur = ph % NR, nxt = (ph + PF) % NR;  // NQ % NR == 0: static across blocks
-            // slot of plane z - R + k is (ph + k) % NQ
-            const V &ctr = zq[(ph + R) % NQ];
-
-            // stage the plane's rows in LDS (double buffered: one barrier per plane)
-            V(*L)[LROWV] = lds[z & 1];
-            L[R + ty][HV + lane] = ctr;
-#pragma unroll
-            for (int i = 0; i < NH; ++i) L[hrow[i]][HV + lane] = halo[ph % NRH][i];
-            reinterpret_cast<T *>(&L[erow][0])[ecol] = edge[cur];
-
-            // fetch plane z+PF's operands (and plane z+R+PF of the queue) while z is computed
-            const int64_t on = (int64_t)(z + PF) * sz;
-            zq[(ph + 2 * R + QE + PF) % NQ] =
-                ldv<T>(a.u_cur + (int64_t)(ZP ? min(z + R + QE + PF, zlast) : z + R + PF) * sz + poff);
-            {
-                const int64_t oh = (int64_t)(z + HPF) * sz;
-#pragma unroll
-                for (int i = 0; i < NH; ++i) halo[(ph + HPF) % NRH][i] = ldv<T>(a.u_cur + oh + hoff[i]);
-            }
-            edge[nxt] = a.u_cur[on + eoff];
-            // (plain loads: non-temporal hints on these read-once streams were measured and
-            // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
-            up[nxt] = ldv<T>(pw + on + poff);
-            Cc[nxt] = ldv<T>(a.C + on + poff);
-            if constexpr (XP != 0) {
-                const int64_t ox = (int64_t)min(z + PF, g.nz - 1) * xplane + xld;
-                xps[nxt] = ldv<T>(a.xp_psi + ox);
-                xzt[nxt] = ldv<T>(a.xp_zeta + ox);
-            }
-            if constexpr (ZP) {  // (planes off the border re-read slab plane 0: one cache line per wave)
-                zps[nxt] = ldv<T>(a.zp_psi + (int64_t)zslab(z + R + PF) * cplane + zco);
-                zzt[nxt] = ldv<T>(a.zp_zeta + (int64_t)zslab(z + (XP == 2 ? 2 * R : 0) + PF) * cplane + zco);
-            }
-            V qi, qi2, gi;
-            if (IMAGE) {
-                const unsigned co = act ? coff : 0u;
-                qi = ld_qf<QB>(a.q_in, (int64_t)z * cplane + co);
-                if (IMAGE == 2) qi2 = ld_qf<QB>(a.q_in2, (int64_t)z * cplane + co);
-                // g is touched once per (other) step: streaming hints keep it from evicting the three
-                // wavefield arrays from the Infinity Cache (adjoint 68 -> 59 us/step at 256^3)
-                gi = ldv_stream<T>(a.g + (int64_t)z * cplane + co);
-            }
-            __syncthreads();
-
-            // X = the HALO elements left of this lane's vector, the vector, the HALO right of it
-            T X[2 * HALO + VL];
-#pragma unroll
-            for (int h = 0; h < HV; ++h) {
-                const V xl = L[R + ty][lane + h], xr = L[R + ty][HV + lane + 1 + h];
-#pragma unroll
-                for (int j = 0; j < VL; ++j) {
-                    X[h * VL + j] = xl.v[j];
-                    X[HALO + VL + h * VL + j] = xr.v[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < VL; ++j) X[HALO + j] = ctr.v[j];
-            V lap, ezv;  // (ezv: the z second difference alone, for the z border's zeta)
-#pragma unroll
-            for (int j = 0; j < VL; ++j) lap.v[j] = ezv.v[j] = T(0);
-#pragma unroll
-            for (int k = R; k >= 1; --k) {
-                const V ym = L[R + ty - k][HV + lane], yp = L[R + ty + k][HV + lane];
-                const V &zm = zq[(ph + R - k) % NQ], &zp = zq[(ph + R + k) % NQ];
-                const T c = a.ck[k];
-#pragma unroll
-                for (int j = 0; j < VL; ++j) {
-                    T t = (X[HALO + j - k] + X[HALO + j + k]) + (ym.v[j] + yp.v[j]) + (zm.v[j] + zp.v[j]);
-                    t = fma(T(-6), X[HALO + j], t);
-                    lap.v[j] = fma(c, t, lap.v[j]);
-                    if (ZP && XP == 1) ezv.v[j] = fma(c, fma(T(-2), X[HALO + j], zm.v[j] + zp.v[j]), ezv.v[j]);
-                }
-            }
-            // x-border CPML: this lane's cells of the border recursion, neighbours through the wave
-            V xterm, xn0, xn1;
-            if constexpr (XP != 0) {
-                T W[2 * HALO + VL];  // [left lane's cells][own][right lane's] of a quantity, zero beyond the wave
-                auto spread = [&](const V &v) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        const T l = __shfl_up(v.v[j], 1, 64), r = __shfl_down(v.v[j], 1, 64);
-                        W[j] = lane == 0 ? T(0) : l;
-                        W[HALO + j] = v.v[j];
-                        W[HALO + VL + j] = lane == 63 ? T(0) : r;
-                    }
-                };
-                const V m0 = xps[cur], m1 = xzt[cur];
-                if (XP == 1) {
-                    // psi' = b psi + a D u;  zeta' = b zeta + a (E_x u + D psi');  term = D psi' + zeta'
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T du = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) du = fma(a.xp_dk1[k], X[HALO + j + k] - X[HALO + j - k], du);
-                        xn0.v[j] = fma(xcb.v[j], m0.v[j], xca.v[j] * du);
-                    }
-                    spread(xn0);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T dp = T(0), ex = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            dp = fma(a.xp_dk[k], W[HALO + j + k] - W[HALO + j - k], dp);
-                            ex = fma(a.ck[k], fma(T(-2), X[HALO + j], X[HALO + j - k] + X[HALO + j + k]), ex);
-                        }
-                        xn1.v[j] = fma(xcb.v[j], m1.v[j], xca.v[j] * (ex + dp));
-                        xterm.v[j] = dp + xn1.v[j];
-                    }
-                } else {
-                    // zt' = b zt + mu;  pt' = b pt - D mu - D (a zt');  term = E_x (a zt') - D (a pt')
-                    V al;
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        xn1.v[j] = fma(xcb.v[j], m1.v[j], X[HALO + j]);
-                        al.v[j] = xca.v[j] * xn1.v[j];
-                    }
-                    spread(al);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T d = T(0), e2 = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            d = fma(a.xp_dk1[k], (X[HALO + j + k] - X[HALO + j - k]) + (W[HALO + j + k] - W[HALO + j - k]), d);
-                            e2 = fma(a.ck[k], fma(T(-2), W[HALO + j], W[HALO + j + k] + W[HALO + j - k]), e2);
-                        }
-                        xn0.v[j] = xcb.v[j] * m0.v[j] - d;
-                        xterm.v[j] = e2;
-                        al.v[j] = xca.v[j] * xn0.v[j];  // (now beta = a pt')
-                    }
-                    spread(al);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        T db = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) db = fma(a.xp_dk[k], W[HALO + j + k] - W[HALO + j - k], db);
-                        xterm.v[j] -= db;
-                    }
-                }
-            }
-
-            // z-border CPML on the march (see the template comment): everything under one wave-uniform test
-            V zterm;
-#pragma unroll
-            for (int j = 0; j < VL; ++j) zterm.v[j] = T(0);
-            if constexpr (ZP) {
-                const unsigned s0 = (unsigned)(z - z0);  // ring slot of plane z - r (slot of plane p: p - z0 + r)
-                const bool near = XP == 1 ? (z < a.npml + R || z + R >= g.nz - a.npml)
-                                          : (z < a.npml + R || z + 2 * R >= g.nz - a.npml);
-                if (XP == 1) {
-                    const int pn = z + R;  // the plane whose psi' is formed now
-                    V pnv;
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) pnv.v[j] = T(0);
-                    const int dn = zdist(pn), dz = zdist(z);
-                    if (near && dn > 0) {
-                        const T an = a.zp_a[dn - 1], bn = a.zp_b[dn - 1];
-                        const V old = zps[cur];
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) {
-                            T du = T(0);
-#pragma unroll
-                            for (int k = 1; k <= R; ++k)
-                                du = fma(a.xp_dk1[k], zq[(ph + 2 * R + k) % NQ].v[j] - zq[(ph + 2 * R - k) % NQ].v[j], du);
-                            pnv.v[j] = fma(bn, old.v[j], an * du);
-                        }
-                        if (pn < z1 && act) stv<T>(a.zp_psi + (int64_t)zslab(pn) * cplane + zco, pnv);
-                    }
-                    zra[(s0 + 2 * R) % NSA][ty][lane] = pnv;
-                    if (near) {
-                        const T az = dz ? a.zp_a[max(dz, 1) - 1] : T(0), bz = dz ? a.zp_b[max(dz, 1) - 1] : T(0);
-                        V dp;
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) dp.v[j] = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            const V pp = zra[(s0 + R + k) % NSA][ty][lane], pm = zra[(s0 + R - k) % NSA][ty][lane];
-#pragma unroll
-                            for (int j = 0; j < VL; ++j) dp.v[j] = fma(a.xp_dk[k], pp.v[j] - pm.v[j], dp.v[j]);
-                        }
-                        V zn;
-                        const V zo = zzt[cur];
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) {
-                            zn.v[j] = fma(bz, zo.v[j], az * (ezv.v[j] + dp.v[j]));
-                            zterm.v[j] = dp.v[j] + zn.v[j];
-                        }
-                        if (dz > 0 && act) stv<T>(a.zp_zeta + (int64_t)zslab(z) * cplane + zco, zn);
-                    }
-                } else {
-                    const int p2 = z + 2 * R, pn = z + R;
-                    V al2, be;
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) al2.v[j] = be.v[j] = T(0);
-                    const int d2 = zdist(p2), dn = zdist(pn);
-                    if (near && d2 > 0) {  // zt'(z + 2r) = b zt + mu;  alpha = a zt'
-                        const T a2 = a.zp_a[d2 - 1], b2 = a.zp_b[d2 - 1];
-                        V zt = zzt[cur];
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) {
-                            zt.v[j] = fma(b2, zt.v[j], zq[(ph + 3 * R) % NQ].v[j]);
-                            al2.v[j] = a2 * zt.v[j];
-                        }
-                        if (p2 < z1 && act) stv<T>(a.zp_zeta + (int64_t)zslab(p2) * cplane + zco, zt);
-                    }
-                    zra[(s0 + 3 * R) % NSA][ty][lane] = al2;
-                    if (near && dn > 0) {  // pt'(z + r) = b pt - D (mu + alpha);  beta = a pt'
-                        const T an = a.zp_a[dn - 1], bn = a.zp_b[dn - 1];
-                        V pt = zps[cur], dw;
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) dw.v[j] = T(0);
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            const V ap = zra[(s0 + 2 * R + k) % NSA][ty][lane], am = zra[(s0 + 2 * R - k) % NSA][ty][lane];
-#pragma unroll
-                            for (int j = 0; j < VL; ++j)
-                                dw.v[j] = fma(a.xp_dk1[k], (zq[(ph + 2 * R + k) % NQ].v[j] + ap.v[j]) -
-                                                               (zq[(ph + 2 * R - k) % NQ].v[j] + am.v[j]), dw.v[j]);
-                        }
-#pragma unroll
-                        for (int j = 0; j < VL; ++j) {
-                            pt.v[j] = bn * pt.v[j] - dw.v[j];
-                            be.v[j] = an * pt.v[j];
-                        }
-                        if (pn < z1 && act) stv<T>(a.zp_psi + (int64_t)zslab(pn) * cplane + zco, pt);
-                    }
-                    zrb[(s0 + 2 * R) % NSB][ty][lane] = be;
-                    if (near) {  // term = E (alpha) - D (beta)
-                        const V a0 = zra[(s0 + R) % NSA][ty][lane];
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            const V ap = zra[(s0 + R + k) % NSA][ty][lane], am = zra[(s0 + R - k) % NSA][ty][lane];
-                            const V bp = zrb[(s0 + R + k) % NSB][ty][lane], bm = zrb[(s0 + R - k) % NSB][ty][lane];
-#pragma unroll
-                            for (int j = 0; j < VL; ++j) {
-                                zterm.v[j] = fma(a.ck[k], fma(T(-2), a0.v[j], ap.v[j] + am.v[j]), zterm.v[j]);
-                                zterm.v[j] = fma(-a.xp_dk[k], bp.v[j] - bm.v[j], zterm.v[j]);
-                            }
-                        }
-                    }
-                }
-            }
-
-            V A = Axy, B = Bxy;
-            if (DAMP) {
-                // d_z(z) from the plane index: a load here would be a VECTOR load (the compiler
-                // cannot prove the profile is not aliased by the u_next stores) whose wait
-                // drains every prefetch in flight
-                const int dist = max(0, max(a.npml - z, z - (g.nz - 1 - a.npml)));
-                if (dist != 0) {
-                    const T dzv = a.dz_scale * (T)(dist * dist);
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        const T d = dxy.v[j] + dzv;
-                        B.v[j] = T(1) - d;
-                        A.v[j] = rcp_nr(T(1) + d);
-                    }
-                }
-            }
-            V q, un, vn;
-#pragma unroll
-            for (int j = 0; j < VL; ++j) {
-                q.v[j] = XP ? Cc[cur].v[j] * (lap.v[j] + (ZP ? xterm.v[j] + zterm.v[j] : xterm.v[j]))
-                            : Cc[cur].v[j] * lap.v[j];
-                if (INC) {  // v' = A (B v + q), u' = u + v'
-                    vn.v[j] = DAMP ? fma(B.v[j], up[cur].v[j], q.v[j]) * A.v[j] : up[cur].v[j] + q.v[j];
-                    un.v[j] = X[HALO + j] + vn.v[j];
-                } else if (DAMP)
-                    un.v[j] = (fma(T(2), X[HALO + j], -B.v[j] * up[cur].v[j]) + q.v[j]) * A.v[j];
-                else
-                    un.v[j] = (T(2) * X[HALO + j] - up[cur].v[j]) + q.v[j];
-            }
-            if constexpr (XP != 0) {
-                if (XMASK && xin && xcells != (1u << VL) - 1u) {  // the lane astride the border's inner edge
-#pragma unroll
-                    for (int j = 0; j < VL; ++j)
-                        if (xcells >> j & 1u) {
-                            a.xp_psi[(int64_t)z * xplane + xld + j] = xn0.v[j];
-                            a.xp_zeta[(int64_t)z * xplane + xld + j] = xn1.v[j];
-                        }
-                } else if (xin) {
-                    stv<T>(a.xp_psi + (int64_t)z * xplane + xld, xn0);
-                    stv<T>(a.xp_zeta + (int64_t)z * xplane + xld, xn1);
-                }
-            }
-            if (act) {
-                if (INC) stv<T>(a.v + (int64_t)z * sz + poff, vn);
-                stv<T>(a.u_prev + (int64_t)z * sz + poff, un);
-                if (SAVE_Q) st_qf<QB>(a.q_out, (int64_t)z * cplane + coff, q);
-                if (IMAGE) {
-#pragma unroll
-                    for (int j = 0; j < VL; ++j) {
-                        gi.v[j] = fma(X[HALO + j], qi.v[j], gi.v[j]);
-                        if (IMAGE == 2) gi.v[j] = fma(up[cur].v[j], qi2.v[j], gi.v[j]);
-                    }
-                    stv_stream<T>(a.g + (int64_t)z * cplane + coff, gi);
-                }
-            }
-        }
-    }
-
-    // Source / residual injection into the points this workgroup has just written.
-    // Wave-uniform and almost always empty; the barrier (which drains this workgroup's
-    // stores, vmcnt(0)) orders the float atomics after the plain stores of u_next.
-    if (a.inj_start) {
-        const int s0 = a.inj_start[bid], s1 = a.inj_start[bid + 1];
-        if (s1 > s0) {
-            __syncthreads();
-            // (bf16 store: the source's own share of the imaging term is added in closed form after the adjoint
-            // sweep, source_image_kernel, instead of being rounded into the store)
-            inject_runs<T, INC, SAVE_Q && !QB>(a, s0, s1, ty * 64 + lane, 64 * TY);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // TILE kernel (2-D, fp32): the 2-D sibling of the stream kernel.  A workgroup of 64 x TY threads
@@ -1002,9 +254,6 @@ __global__ __launch_bounds__(64 * TY) void step2d_tile(StepArgs<float> a, GridDe
     }
 }
 
-// x tiles of `tile_x` elements: 64 lanes x one 16-byte vector (256 floats / 128 doubles)
-static inline int stream_nxt(const GridDesc &g, int tile_x) { return (int)(round_up(g.nx, tile_x) / tile_x); }
-
 int stream_tile_of(const GridDesc &g, const StreamTuning &t, int z, int y, int x) {
     const int nxt = stream_nxt(g, t.tile_x);
     if (g.ndim == 2) return (z / t.ty) * nxt + x / t.tile_x;
@@ -1036,18 +285,6 @@ bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, b
     const int tw = t.tile_x, nxt = stream_nxt(g, tw);
     // each border and the r cells it reaches into lie inside ONE tile row, i.e. inside one wave
     return tw >= npml + g.r && g.nx - (nxt - 1) * tw >= npml + g.r;
-}
-
-bool stream_zpml_supported(const GridDesc &g, const StreamTuning &t, int npml, bool reverse) {
-    // (on top of stream_xpml_supported) chunk seams 2 r planes clear of the borders: a chunk that starts or ends inside
-    // a border's reach would need its neighbour's psi'.  The adjoint's rings fit the LDS with 4-row tiles only.
-    const int r = g.r, zc = t.zchunk > 0 ? t.zchunk : g.nz;
-    (void)reverse;
-    if (g.nz <= 2 * (npml + 2 * r)) return false;
-    if (t.ty != 4) return false;  // 8-row tiles: the rings' registers spill (forward) / their LDS overflows (adjoint)
-    for (int zb = zc; zb < g.nz; zb += zc)
-        if (zb < npml + 2 * r || zb > g.nz - npml - 2 * r) return false;
-    return true;
 }
 
 StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
@@ -1114,192 +351,6 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
         }
     }
     return best;
-}
-
-template <typename T, int R, int TY, bool DAMP, bool FULL, int PF>
-static hipError_t launch_stream_full(const GridDesc &g, const StepArgs<T> &a, int zchunk, int tw, hipStream_t s) {
-    const int nxt = stream_nxt(g, tw);
-    const int nyt = (g.ny + TY - 1) / TY;
-    const int nzc = (g.nz + zchunk - 1) / zchunk;
-    const int nblk = nxt * nyt * nzc;
-    const int nrb = (a.rec_out && a.nrec > 0) ? (a.nrec + 64 * TY * 4 - 1) / (64 * TY * 4) : 0;
-    dim3 block(64, TY), grid(nblk + nrb);
-    static const bool no_remap = getenv("FWI_STREAM_NOREMAP") != nullptr;  // tuning hook
-    if (no_remap) zchunk = -zchunk;
-    if constexpr (std::is_same<T, float>::value) {
-        if (a.v) {  // increment form (fp32 only; the adjoint sweep images one pairing per step)
-            if constexpr (R == 4 && !DAMP) {
-                if (a.xp_mode == 1 && !a.xp_partial) {  // ... with the x border's recursion in the lanes (the term joins q, hence v' and u')
-                    if (a.q_out)
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true, false, 1>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    else
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 1>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    return hipGetLastError();
-                }
-                if (a.xp_mode == 2 && !a.xp_partial) {
-                    if (a.q_in)
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true, false, 2>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    else
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 2>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    return hipGetLastError();
-                }
-                if (a.xp_mode == 1) {  // (border width not a multiple of 4: masked stores)
-                    if (a.q_out)
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true, false, 3>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    else
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 3>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    return hipGetLastError();
-                }
-                if (a.xp_mode == 2) {
-                    if (a.q_in)
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true, false, 4>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    else
-                        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true, false, 4>), grid, block, 0, s,
-                                           a, g, zchunk, nxt, nyt, nblk, tw);
-                    return hipGetLastError();
-                }
-            }
-            if (a.q_out)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, true>), grid, block, 0, s, a, g,
-                                   zchunk, nxt, nyt, nblk, tw);
-            else if (a.q_in)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, true>), grid, block, 0, s, a, g,
-                                   zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, true>), grid, block, 0, s, a, g,
-                                   zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-    }
-    if constexpr (std::is_same<T, float>::value) {
-        if (a.q_bf16 && (a.q_out || a.q_in)) {  // forward term stored in bf16
-            if (a.q_out)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, true>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else if (a.q_in2)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, true>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, true>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-    }
-    if constexpr (std::is_same<T, float>::value && R == 4 && !DAMP) {
-        if constexpr (TY == 4) {  // (4-row tiles only: with 8 rows the rings' registers spill / the adjoint's LDS overflows)
-            if (a.xp_mode == 1 && a.zp_on) {  // x border in the lanes + z border on the march, forward recursion
-                if (a.q_out)
-                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1, true>), grid, block,
-                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-                else
-                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 1, true>), grid, block,
-                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-                return hipGetLastError();
-            }
-        }
-        if constexpr (TY == 4) {
-            if (a.xp_mode == 2 && a.zp_on) {
-                if (a.q_in && a.q_in2)
-                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 2, true>), grid, block,
-                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-                else if (a.q_in)
-                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 2, true>), grid, block,
-                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-                else
-                    hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 2, true>), grid, block,
-                                       0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-                return hipGetLastError();
-            }
-        }
-        if (a.xp_mode == 1 && !a.xp_partial) {  // x-border CPML in the lanes, forward recursion
-            if (a.q_out)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 1>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 1>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-        if (a.xp_mode == 2 && !a.xp_partial) {  // ... its transpose (the adjoint sweep)
-            if (a.q_in && a.q_in2)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 2>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else if (a.q_in)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 2>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 2>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-        if (a.xp_mode == 1) {  // ... borders of 10, 14, ... cells: masked stores in the straddling lane
-            if (a.q_out)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF, false, false, 3>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 3>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-        if (a.xp_mode == 2) {  // ... its transpose (the adjoint sweep)
-            if (a.q_in && a.q_in2)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF, false, false, 4>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else if (a.q_in)
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF, false, false, 4>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            else
-                hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF, false, false, 4>), grid, block, 0, s,
-                                   a, g, zchunk, nxt, nyt, nblk, tw);
-            return hipGetLastError();
-        }
-    }
-    if (a.q_out)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, true, 0, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk, tw);
-    else if (a.q_in && a.q_in2)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 2, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk, tw);
-    else if (a.q_in)
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 1, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk, tw);
-    else
-        hipLaunchKernelGGL((step3d_stream<T, R, TY, DAMP, false, 0, FULL, PF>), grid, block, 0, s, a, g,
-                           zchunk, nxt, nyt, nblk, tw);
-    return hipGetLastError();
-}
-
-template <typename T, int R, int TY, bool DAMP>
-static hipError_t launch_stream_mode(const GridDesc &g, const StepArgs<T> &a, int zchunk, int tw, hipStream_t s) {
-    // FULL: every thread of every tile owns grid points, so the stores need no predicate.
-    // Prefetch depth: PF = 1 plane ahead measured best (256^3: 39.5 us/step vs 40.0 / 40.2 for
-    // PF = 2 / 3; 512^3 equal), i.e. the kernel is throughput- not latency-bound; deeper rings
-    // only cost registers.  The template parameter stays for re-tuning.
-    if (g.nx % (64 * VecOf<T>::VL) == 0 && g.ny % TY == 0 && tw == 64 * VecOf<T>::VL)
-        return launch_stream_full<T, R, TY, DAMP, true, 1>(g, a, zchunk, tw, s);
-    return launch_stream_full<T, R, TY, DAMP, false, 1>(g, a, zchunk, tw, s);
-}
-
-template <typename T, int R>
-static hipError_t launch_stream_r(const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t, hipStream_t s) {
-    const int zc = t.zchunk > 0 ? t.zchunk : g.nz;
-    if (a.damp) {
-        switch (t.ty) {
-            case 4: return launch_stream_mode<T, R, 4, true>(g, a, zc, t.tile_x, s);
-            default: return launch_stream_mode<T, R, 8, true>(g, a, zc, t.tile_x, s);
-        }
-    }
-    switch (t.ty) {
-        case 4: return launch_stream_mode<T, R, 4, false>(g, a, zc, t.tile_x, s);
-        default: return launch_stream_mode<T, R, 8, false>(g, a, zc, t.tile_x, s);
-    }
 }
 
 template <typename T>

@@ -308,10 +308,10 @@ static hipError_t launch_pair_r(const GridDesc &g, const Pair3dArgs &a, int zchu
     const int nth = 64 * PAIR3D_TY;
     const int nrb = ((a.rec_out0 || a.rec_out1) && a.nrec > 0) ? (a.nrec + nth * 4 - 1) / (nth * 4) : 0;
     dim3 block(64, PAIR3D_TY), grid(nblk + nrb);
-    if (a.damp)
-        hipLaunchKernelGGL((step3d_pair<R, true>), grid, block, 0, s, a, g, zchunk, nxt, nyt, nblk, tw);
-    else
-        hipLaunchKernelGGL((step3d_pair<R, false>), grid, block, 0, s, a, g, zchunk, nxt, nyt, nblk, tw);
+    // (undamped grids only since round 4: the damped O(8) instantiation spilled 70 registers -- 204 B of scratch per lane --
+    // and the path is an opt-in negative result; fwi_create keeps sponge contexts on the single-step kernel)
+    if (a.damp) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((step3d_pair<R, false>), grid, block, 0, s, a, g, zchunk, nxt, nyt, nblk, tw);
     return hipGetLastError();
 }
 

@@ -395,49 +395,45 @@ __global__ __launch_bounds__(256) void pml_kernel_x4(PmlArgs<float> p, GridDesc 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LINE form of the z / y border (3-D): one launch per axis and time step instead of three slab passes.
+// LINE form of the z / y border (3-D): ONE launch per time step for both axes, BEFORE the step kernel.
 //
 // Along its own axis the border recursion is one-dimensional: psi'(i), zeta'(i) and the term of cell i need the field
 // and the memory variables of the SAME (other two coordinates) line only.  So a thread owns one lane of x (two cells: 8
-// bytes in fp32, 16 in fp64 -- measured best, DESIGN.md s.4 CPML) at a fixed other coordinate and marches along the axis through the border and the r cells its term reaches, in blocks of
-// four cells: the field values of the line sit in a register window (every u is loaded once instead of 2r + 1 times),
-// the new psi' (adjoint: alpha = a zt', beta = a pt') in a second one -- they are never re-read from memory, which is
-// what forced the slab form into three passes -- and every memory variable is read once and written once per step,
-// with streaming hints: at 256^3 the six of them (50 MB) are what pushed the wavefields out of the Infinity Cache.
-// The inputs of block k + 1 are in flight while block k is computed.  All accesses are coalesced along x.
+// bytes in fp32, 16 in fp64 -- measured best, DESIGN.md s.4 CPML) at a fixed other coordinate and marches along the
+// axis through the border and the r cells its term reaches, in blocks of four cells: the field values of the line sit
+// in a register window (every u is loaded once instead of 2r + 1 times), the new psi' (adjoint: alpha = a zt',
+// beta = a pt') in a second one -- they are never re-read from memory, which is what forced the slab form into three
+// passes -- and every memory variable is read once and written once per step, with streaming hints: at 256^3 the six
+// of them (50 MB) are what pushed the wavefields out of the Infinity Cache.  The inputs of block k + 1 are in flight
+// while block k is computed.  All accesses are coalesced along x.
 // Off the border a = b = 0 make psi' = zeta' = 0 by themselves, so one loop body serves the low border, the high
 // border and the case of the two (nearly) meeting (n < 2 npml + 3 r: one segment over the whole axis); loads are clamped
-// instead of branched around, stores predicated.  Runs AFTER the step kernel: reads u^n (adjoint: the newest mu) and
-// the old memory variables, adds C * term to u' (v', q).
-#ifndef PML_LINE_BS1
-#define PML_LINE_BS1 8
-#endif
-// Diagnostic builds only (-DPML_LINE_ABLATE=bits; results are wrong): 1 = no arithmetic (old values stored back), 2 = no
-// read-modify-write of u' / v' / q, 4 = no memory-variable stores, 8 = no field loads (u window stays zero), 16 = no
-// memory-variable loads
-#ifndef PML_LINE_ABLATE
-#define PML_LINE_ABLATE 0
-#endif
-template <typename T, int R, int D, bool REV, int VL, bool HV, bool HQ>
-__global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
-    constexpr bool NT = true;  // (streaming hints on the memory variables: read once, written once per step)
-    // cells per block = the loads a thread keeps in flight (5-7 per cell).  (4-byte lanes with 8 cells per block were
-    // measured too: no faster; only VL = 2 is instantiated)
-    constexpr int BS = VL == 1 ? PML_LINE_BS1 : 4;
+// instead of branched around, stores predicated.
+//
+// Round 4: the launch runs BEFORE the step kernel and HANDS THE TERM OVER instead of adding it to u' afterwards.  The
+// term T_d = D psi_d' + zeta_d' (adjoint: E alpha_d - D beta_d) depends on the newest field and the memory variables
+// only, so it is written to an array compact over the axis' shell (PmlArgs::tz / ty, 4 B per shell cell) and the step
+// kernel forms q = C (L u + sum_d T_d + ...) in one go.  Against the round-3 form (after the step: re-read C, read-
+// modify-write u' -- and v' in increment form, q in a store sweep) a shell cell costs 4 B written + 4 B read instead of
+// 4 B (C) + 8 B (u') [+ 8 B (v') + 8 B (q)], the kernel has no optional operands left, and the z and the y lines share
+// ONE launch (block ranges): 2 launches per time step instead of 3.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PML_LINE_MAXC = 192;  // rows of the coefficient tables (pml_line_axes checks)
+
+template <typename T, int R, int D, bool REV, int VL>
+__device__ __forceinline__ void pml_line_body(const PmlArgs<T> &p, const GridDesc &g, int bxi, int boi, int seg, T *ca,
+                                              T *cb, int *cin) {
+    constexpr int BS = 4;                          // cells per block = the loads a thread keeps in flight (3 per cell)
     constexpr int W = (2 * R + BS - 1) / BS * BS;  // warm-up cells ahead of the segment (whole blocks)
     constexpr int NU = BS + 3 * R, NP = BS + 2 * R;
-    constexpr int MAXC = 192;                      // rows of the coefficient tables (launch_pml_lines checks)
     using V = vecn<T, VL>;
     typedef T ntv_t __attribute__((ext_vector_type(VL > 1 ? VL : 2)));
     static_assert(D == 0 || D == 1, "z or y axis");
-    __shared__ T ca[MAXC], cb[MAXC];
-    __shared__ int cin[MAXC];  // 1 = a border row this segment owns (and stores)
 
     const int n = D == 0 ? g.nz : g.ny, npml = p.npml;
     // (the low segment computes memory variables up to 2r rows past its end -- all zero off the border, but not if the
     // high border begins there: then one thread takes the whole axis, in order)
     const bool merged = n < 2 * npml + 3 * R;
-    const int seg = blockIdx.z;
     const int ib = (merged || seg == 0) ? 0 : n - npml - R;
     const int ie = (merged || seg == 1) ? n : npml + R;
     // First (warm-up) block: W cells ahead serve any case, but the blocks that would only form zeros are skipped when the
@@ -448,7 +444,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     const int is = (R % BS == 0) ? ib - (REV ? (high ? R : 2 * R) : (high ? 0 : R)) : ib - W;
     const int c0 = is - R;                // grid row of table entry 0
     const int nrows = (ie - is + BS - 1) / BS * BS + 3 * R + BS;
-    for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < nrows && i < MAXC; i += blockDim.x * blockDim.y) {
+    for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < nrows && i < PML_LINE_MAXC; i += blockDim.x * blockDim.y) {
         // (a segment sees its OWN border only: its last block may look a few rows into the other one, which the
         // other segment's threads are advancing at the same time)
         const int j = c0 + i;
@@ -459,8 +455,8 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     }
     __syncthreads();
 
-    const int xv = blockIdx.x * blockDim.x + threadIdx.x;
-    const int o = blockIdx.y * blockDim.y + threadIdx.y;  // the other coordinate: y (D = 0) or z (D = 1)
+    const int xv = bxi * blockDim.x + threadIdx.x;
+    const int o = boi * blockDim.y + threadIdx.y;  // the other coordinate: y (D = 0) or z (D = 1)
     const int no = D == 0 ? g.ny : g.nz;
     const bool act = VL * xv < g.cx && o < no;
     const int x = act ? VL * xv : 0, oc = act ? o : 0;
@@ -469,8 +465,12 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     const int64_t fbase = g.off0 + (int64_t)oc * (D == 0 ? g.sy : g.sz) + x;          // padded index of row 0
     const int64_t ast = D == 0 ? (int64_t)g.ny * g.cx : g.cx;                         // memory-variable stride
     const int64_t abase = D == 0 ? (int64_t)oc * g.cx + x : (int64_t)oc * nslab * g.cx + x;
-    const int64_t qst = D == 0 ? (int64_t)g.ny * g.cx : g.cx;                         // compact stride (q)
-    const int64_t qbase = D == 0 ? (int64_t)oc * g.cx + x : (int64_t)oc * g.ny * g.cx + x;
+    // the term's array: shell row s of this line at tbase + s * tst
+    const int nsh = pml_shell_rows(n, npml, R);
+    const int64_t tst = D == 0 ? (int64_t)g.ny * g.cx : g.cx;
+    const int64_t tbase = D == 0 ? (int64_t)oc * g.cx + x : (int64_t)oc * nsh * g.cx + x;
+    T *const tout = D == 0 ? p.tz : p.ty;
+    const int tshift = (merged || seg == 0) ? 0 : n - nsh;  // shell row of grid row i = i - tshift
     T *const m0 = REV ? p.zeta[D] : p.psi[D];   // the variable advanced first:  psi / zt
     T *const m1 = REV ? p.psi[D] : p.zeta[D];   // ... and second:               zeta / pt
 
@@ -483,59 +483,42 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     };
     auto ldm = [&](const T *m, int j) {
         const T *q = m + abase + (int64_t)slab(j) * ast;
-        if constexpr (NT && VL > 1) {
+        if constexpr (VL > 1) {
             const ntv_t v = __builtin_nontemporal_load(reinterpret_cast<const ntv_t *>(q));
             V r;
 #pragma unroll
             for (int t = 0; t < VL; ++t) r.v[t] = v[t];
             return r;
-        } else if constexpr (NT) {
+        } else {
             V r;
             r.v[0] = __builtin_nontemporal_load(q);
             return r;
-        } else {
-            return ldn<T, VL>(q);
         }
     };
     auto stm = [&](T *m, int j, const V &v) {
         T *q = m + abase + (int64_t)slab(j) * ast;
-        if constexpr (NT && VL > 1) {
+        if constexpr (VL > 1) {
             ntv_t w;
 #pragma unroll
             for (int t = 0; t < VL; ++t) w[t] = v.v[t];
             __builtin_nontemporal_store(w, reinterpret_cast<ntv_t *>(q));
-        } else if constexpr (NT) {
-            __builtin_nontemporal_store(v.v[0], q);
         } else {
-            stn<T, VL>(q, v);
+            __builtin_nontemporal_store(v.v[0], q);
         }
     };
     struct In {
         V un[BS];  // new field rows of the window
         V o0[BS];  // old values of the variable advanced first, at its new rows
         V o1[BS];  // ... of the second
-        V c[BS], up[BS], vv[BS], qq[BS];  // C, u', v', q of the block's own rows
     };
     // rows whose inputs a block at i0 needs (REV: zt sits 2r ahead like the field, pt r ahead; forward: psi r ahead,
     // zeta at the block's own rows)
     auto issue = [&](int i0, In &in) {
-        const bool out = i0 >= ib;
 #pragma unroll
         for (int t = 0; t < BS; ++t) {
-            if (!(PML_LINE_ABLATE & 8)) in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
-            if (!(PML_LINE_ABLATE & 16)) {
-                in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
-                in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
-            }
-            const int jr = out ? min(i0 + t, ie - 1) : ib;  // (warm-up blocks re-read one row: cache hits)
-            if (!(PML_LINE_ABLATE & 2)) {
-                in.c[t] = ldf(p.C, jr);
-                in.up[t] = ldf(p.u_next, jr);
-            }
-            // (vv / qq stay unset when the option is off: giving them values costs 64 live registers and a quarter of
-            // the launch's speed -- 256^3 / npml 16 forward 100 -> 126 us/step, measured)
-            if constexpr (HV && !(PML_LINE_ABLATE & 2)) in.vv[t] = ldf(p.v, jr);
-            if constexpr (HQ && !(PML_LINE_ABLATE & 2)) in.qq[t] = ldn<T, VL>(p.q_out + qbase + (int64_t)min(max(jr, 0), n - 1) * qst);
+            in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
+            in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
+            in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
         }
     };
 
@@ -581,7 +564,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     v.v[q] = fma(bv, cur.o0[t].v[q], av * du);
                 }
                 Pw[2 * R + t] = v;
-                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + R + t]) stm(m0, j, v);
+                if (act && cin[tb + R + t]) stm(m0, j, v);
             }
             // zeta'(i) = b zeta + a (E u + D psi');  term = D psi' + zeta'   (warm-up blocks: nothing to form)
             if (out)
@@ -589,7 +572,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
             for (int t = 0; t < BS; ++t) {
                 const int i = i0 + t;
                 const T av = ca[tb + t], bv = cb[tb + t];
-                V zn, add;
+                V zn, term;
 #pragma unroll
                 for (int q = 0; q < VL; ++q) {
                     T dp = T(0), e2 = T(0);
@@ -599,28 +582,11 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                         e2 = fma(p.ck[k], fma(T(-2), Uw[R + t].v[q], Uw[R + t + k].v[q] + Uw[R + t - k].v[q]), e2);
                     }
                     zn.v[q] = fma(bv, cur.o1[t].v[q], av * (e2 + dp));
-                    add.v[q] = cur.c[t].v[q] * (dp + zn.v[q]);
+                    term.v[q] = dp + zn.v[q];
                 }
-                const bool row = act && out && i < ie;
-                if (!(PML_LINE_ABLATE & 4) && row && cin[tb + t]) stm(m1, i, zn);
-                if (!(PML_LINE_ABLATE & 2) && row) {
-                    V un = cur.up[t];
-#pragma unroll
-                    for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
-                    stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
-                    if constexpr (HV) {
-                        V w = cur.vv[t];
-#pragma unroll
-                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
-                        stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
-                    }
-                    if constexpr (HQ) {
-                        V w = cur.qq[t];
-#pragma unroll
-                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
-                        stn<T, VL>(p.q_out + qbase + (int64_t)i * qst, w);
-                    }
-                }
+                const bool row = act && i < ie;
+                if (row && cin[tb + t]) stm(m1, i, zn);
+                if (row) stn<T, VL>(tout + tbase + (int64_t)(i - tshift) * tst, term);
             }
         } else {
             // zt'(j) = b zt + mu(j), alpha = a zt',  j = i0 + 2r + t
@@ -635,7 +601,7 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     zt.v[q] = fma(bv, cur.o0[t].v[q], cur.un[t].v[q]);
                     Uw[3 * R + t].v[q] = av * zt.v[q];
                 }
-                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + 2 * R + t]) stm(m0, j, zt);
+                if (act && cin[tb + 2 * R + t]) stm(m0, j, zt);
             }
             // pt'(j) = b pt - D (mu + alpha), beta = a pt',  j = i0 + r + t
 #pragma unroll
@@ -654,14 +620,14 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                     pt.v[q] = bv * cur.o1[t].v[q] - d;
                     Pw[2 * R + t].v[q] = av * pt.v[q];
                 }
-                if (!(PML_LINE_ABLATE & 4) && act && cin[tb + R + t]) stm(m1, j, pt);
+                if (act && cin[tb + R + t]) stm(m1, j, pt);
             }
             // term(i) = E alpha - D beta
             if (out)
 #pragma unroll
             for (int t = 0; t < BS; ++t) {
                 const int i = i0 + t;
-                V add;
+                V term;
 #pragma unroll
                 for (int q = 0; q < VL; ++q) {
                     T e2 = T(0), db = T(0);
@@ -670,26 +636,9 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
                         e2 = fma(p.ck[k], fma(T(-2), Uw[R + t].v[q], Uw[R + t + k].v[q] + Uw[R + t - k].v[q]), e2);
                         db = fma(p.dk[k], Pw[R + t + k].v[q] - Pw[R + t - k].v[q], db);
                     }
-                    add.v[q] = cur.c[t].v[q] * (e2 - db);
+                    term.v[q] = e2 - db;
                 }
-                if (!(PML_LINE_ABLATE & 2) && act && out && i < ie) {
-                    V un = cur.up[t];
-#pragma unroll
-                    for (int q = 0; q < VL; ++q) un.v[q] += add.v[q];
-                    stn<T, VL>(p.u_next + fbase + (int64_t)i * gs, un);
-                    if constexpr (HV) {
-                        V w = cur.vv[t];
-#pragma unroll
-                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
-                        stn<T, VL>(p.v + fbase + (int64_t)i * gs, w);
-                    }
-                    if constexpr (HQ) {
-                        V w = cur.qq[t];
-#pragma unroll
-                        for (int q = 0; q < VL; ++q) w.v[q] += add.v[q];
-                        stn<T, VL>(p.q_out + qbase + (int64_t)i * qst, w);
-                    }
-                }
+                if (act && i < ie) stn<T, VL>(tout + tbase + (int64_t)(i - tshift) * tst, term);
             }
 #pragma unroll
             for (int k = 0; k < NP - BS; ++k) Mw[k] = Mw[k + BS];
@@ -702,55 +651,64 @@ __global__ __launch_bounds__(256) void pml_line(PmlArgs<T> p, GridDesc g) {
     }
 }
 
-// Axes (bit mask: z = 1, y = 2) the line form takes for this grid; the slab phases keep the rest.
-// (table rows for the largest block size, PML_LINE_BS1)
+// One launch, both axes: blocks [0, nbz) march the z lines, the rest the y lines (each range: x blocks fastest, then
+// the other coordinate, then the segment).  nbz = 0 / nby = 0: that axis is not taken.
+template <typename T, int R, bool REV, int VL>
+__global__ __launch_bounds__(256) void pml_line_t(PmlArgs<T> p, GridDesc g, int gx, int goz, int nbz, int goy) {
+    __shared__ T ca[PML_LINE_MAXC], cb[PML_LINE_MAXC];
+    __shared__ int cin[PML_LINE_MAXC];  // 1 = a border row this segment owns (and stores)
+    int b = blockIdx.x;
+    if (b < nbz) {
+        const int bxi = b % gx, t = b / gx;
+        pml_line_body<T, R, 0, REV, VL>(p, g, bxi, t % goz, t / goz, ca, cb, cin);
+    } else {
+        b -= nbz;
+        const int bxi = b % gx, t = b / gx;
+        pml_line_body<T, R, 1, REV, VL>(p, g, bxi, t % goy, t / goy, ca, cb, cin);
+    }
+}
+
+// Axes (bit mask: z = 1, y = 2) the line form takes for this grid: both or none (the step kernels take the handed-over
+// term of both axes together); the slab phases keep the rest.
 int pml_line_axes(const GridDesc &g, int npml) {
     const bool off = getenv("FWI_NO_PML_LINES") != nullptr;  // (read per context: the tests switch it)
     if (off || g.ndim != 3 || npml < 1) return 0;
-    int axes = 0;
     const int nd[2] = {g.nz, g.ny};
     for (int d = 0; d < 2; ++d) {
-        constexpr int B = PML_LINE_BS1;
+        constexpr int B = 4;
         const int n = nd[d], r = g.r, W = (2 * r + B - 1) / B * B;
         const int len = n < 2 * npml + 3 * r ? n : npml + r;            // cells of a segment
         const int rows = (len + W + B - 1) / B * B + 3 * r + B;         // table rows the kernel fills
-        if (rows <= 192 && n >= 1) axes |= 1 << d;
+        if (rows > PML_LINE_MAXC || n < 1) return 0;
     }
-    return axes;
+    return 3;
 }
 
 // 8-byte lanes for fp32, 16-byte for fp64 (256^3 / npml 16 forward, us/step: 4-byte lanes 103-106, 8-byte 99-101,
-// 16-byte 110); the optional operands (v' of the increment form, q of a store sweep) are compile-time: as run-time
-// branches around their loads and stores they were a third of the loop's instructions.
-template <typename T, int R, int D, bool REV>
-static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s) {
+// 16-byte 110: measured on the round-3 form).
+template <typename T, int R, bool REV>
+static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
     constexpr int VL = 2;
-    const int n = D == 0 ? g.nz : g.ny, no = D == 0 ? g.ny : g.nz;
     const int nxv = g.cx / VL;
     const int bx = nxv <= 16 ? 16 : nxv <= 32 ? 32 : 64, by = 256 / bx;
-    const dim3 block(bx, by);
-    const dim3 grid((nxv + bx - 1) / bx, (no + by - 1) / by, n < 2 * p.npml + 3 * R ? 1 : 2);
-    if (p.v && p.q_out) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, true, true>), grid, block, 0, s, p, g);
-    else if (p.v) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, true, false>), grid, block, 0, s, p, g);
-    else if (p.q_out) hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, false, true>), grid, block, 0, s, p, g);
-    else hipLaunchKernelGGL((pml_line<T, R, D, REV, VL, false, false>), grid, block, 0, s, p, g);
-}
-
-template <typename T, int R, int D>
-static void launch_pml_line_axis(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s) {
-    if (reverse) launch_pml_line_rev<T, R, D, true>(g, p, s);
-    else launch_pml_line_rev<T, R, D, false>(g, p, s);
+    const int gx = (nxv + bx - 1) / bx;
+    const int goz = (g.ny + by - 1) / by, goy = (g.nz + by - 1) / by;
+    const int nbz = (axes & 1) ? gx * goz * (g.nz < 2 * p.npml + 3 * R ? 1 : 2) : 0;
+    const int nby = (axes & 2) ? gx * goy * (g.ny < 2 * p.npml + 3 * R ? 1 : 2) : 0;
+    if (nbz + nby == 0) return;
+    hipLaunchKernelGGL((pml_line_t<T, R, REV, VL>), dim3(nbz + nby), dim3(bx, by), 0, s, p, g, gx, goz, nbz, goy);
 }
 
 template <typename T, int R>
 static hipError_t launch_pml_lines_r(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes) {
-    if (axes & 1) launch_pml_line_axis<T, R, 0>(g, p, reverse, s);
-    if (axes & 2) launch_pml_line_axis<T, R, 1>(g, p, reverse, s);
+    if (reverse) launch_pml_line_rev<T, R, true>(g, p, s, axes);
+    else launch_pml_line_rev<T, R, false>(g, p, s, axes);
     return hipGetLastError();
 }
 
 template <typename T>
 hipError_t launch_pml_lines(const GridDesc &g, const PmlArgs<T> &p, int reverse, hipStream_t s, int axes) {
+    if (((axes & 1) && !p.tz) || ((axes & 2) && !p.ty)) return hipErrorInvalidValue;
     switch (g.r) {
         case 1: return launch_pml_lines_r<T, 1>(g, p, reverse, s, axes);
         case 2: return launch_pml_lines_r<T, 2>(g, p, reverse, s, axes);

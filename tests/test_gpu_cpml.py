@@ -41,8 +41,7 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
     ((40, 36, 64), 8, 10, 30.0, "float32", TOL32, "step3d_stream", {}),
     ((36, 30, 300), 8, 14, 0.0, "float32", TOL32, "step3d_stream", {"update_form": "increment", "ckpt_interval": 16}),
     ((26, 22, 256), 8, 6, 20.0, "float32", TOL32, "step3d_stream", {}),           # (FULL path)
-    # grids on which the z border can ride on the z march as well (stream_zpml_supported; opt-in, see
-    # test_cpml_z_border_on_the_march) -- by default their z and y borders run as line launches
+    # thin grids with several z chunks per tile: chunk seams between / inside the borders' shells
     ((64, 20, 48), 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": 32}),   # a seam between the two borders
     ((56, 18, 44), 8, 8, 0.0, "float32", TOL32, "step3d_stream", {"zchunk": 56}),    # one chunk holds both
     ((70, 17, 40), 8, 12, 25.0, "float32", TOL32, "step3d_stream", {"zchunk": 35, "ckpt_interval": 20}),
@@ -72,6 +71,18 @@ CASES = [  # shape, order, npml, alpha, dtype, tol, kernel, engine options
 ]
 
 
+# 3-D stream-kernel cases again with 8-row tiles (FWI_STREAM_TY=8): the shape stream_default_tuning picks for every
+# grid past the Infinity Cache (>= 272^3) -- none of which an oracle finishes in seconds, so the hook brings the tile
+# shape to the oracle-sized grids instead (missing #1).  Same bar.
+CASES_TY8 = [c for c in CASES if c[6] == "step3d_stream" and len(c[0]) == 3]
+
+
+@pytest.mark.parametrize("shape,order,npml,alpha,dtype,tol,kern,kw", CASES_TY8)
+def test_cpml_vs_oracle_with_8_row_tiles(gpu, monkeypatch, shape, order, npml, alpha, dtype, tol, kern, kw):
+    monkeypatch.setenv("FWI_STREAM_TY", "8")
+    test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw)
+
+
 @pytest.mark.parametrize("shape,order,npml,alpha,dtype,tol,kern,kw", CASES)
 def test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw):
     rng = np.random.default_rng(11)
@@ -95,22 +106,18 @@ def test_cpml_vs_oracle(gpu, shape, order, npml, alpha, dtype, tol, kern, kw):
         gg = e.gradient()
         dg2 = e.forward(None, (src, wav), rec, save=False)  # the memory variables restart from zero
     assert np.array_equal(dg, dg2) or rel(dg2, dg) < 1e-6
-    assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (rel(dg, d), rel(ag, a), rel(gg, g))
+    # (flat tolerance on all three since round 4: profiles/r03_parity.json measures <= 6e-6 on every fp32 case)
+    assert rel(dg, d) < tol and rel(ag, a) < tol and rel(gg, g) < tol, (rel(dg, d), rel(ag, a), rel(gg, g))
 
 
-@pytest.mark.parametrize("shape,npml,alpha,kw", [((64, 20, 48), 8, 30.0, {"zchunk": 32}), ((56, 18, 44), 8, 0.0, {"zchunk": 56}),
-                                                 ((70, 17, 40), 12, 25.0, {"zchunk": 35, "ckpt_interval": 20})])
-def test_cpml_z_border_on_the_march(gpu, monkeypatch, shape, npml, alpha, kw):
-    """The z border inside step3d_stream's z march (forward sweeps): correct, but since the line launches exist it
-    costs the step kernel more than the launch it saves (DESIGN.md s.4 CPML), so it is opt-in: FWI_STREAM_ZPML=1."""
-    monkeypatch.setenv("FWI_STREAM_ZPML", "1")
-    test_cpml_vs_oracle(gpu, shape, 8, npml, alpha, "float32", TOL32, "step3d_stream", kw)
-
-
-@pytest.mark.parametrize("kw", [{}, {"update_form": "increment"}, {"dtype": "float64"}])
-def test_cpml_line_launches_equal_the_slab_path(gpu, monkeypatch, kw):
-    """The same shot with the z / y borders as line launches (default) and as the three slab phases per axis
-    (FWI_NO_PML_LINES=1): seismograms, F^T r and gradient agree to round-off."""
+@pytest.mark.parametrize("stream_ty", [None, "8"])
+@pytest.mark.parametrize("kw", [{}, {"update_form": "increment"}, {"dtype": "float64"}, {"kernel": "point"}])
+def test_cpml_line_launches_equal_the_slab_path(gpu, monkeypatch, kw, stream_ty):
+    """The same shot with the z / y borders' term handed over by the line launch (default; the x border then in the
+    stream kernel's lanes) and with all three axes as slab phases around the step kernel (FWI_NO_PML_LINES=1):
+    seismograms, F^T r and gradient agree to round-off.  4- and 8-row tiles; the point kernel takes the term too."""
+    if stream_ty:
+        monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
     rng = np.random.default_rng(8)
     shape, npml, nt = (44, 40, 48), 8, 60
     c = 1900.0 + 700.0 * rng.random(shape)
@@ -130,15 +137,6 @@ def test_cpml_line_launches_equal_the_slab_path(gpu, monkeypatch, kw):
     tol = 1e-12 if kw.get("dtype") == "float64" else 1e-5  # (fp32: the two forms sum the second difference differently)
     for x, y in zip(*out):
         assert rel(x, y) < tol
-
-
-@pytest.mark.parametrize("shape,zchunk", [((64, 20, 48), 32), ((56, 18, 44), 56)])
-def test_cpml_z_border_on_the_march_in_the_adjoint_sweep_too(gpu, monkeypatch, shape, zchunk):
-    """The adjoint form of the in-kernel z border (two LDS rings) is built and correct but SLOWER than the slab
-    launches it replaces (DESIGN.md s.4 CPML), so it is opt-in: FWI_STREAM_ZPML_REV=1.  Same bar as everything else."""
-    monkeypatch.setenv("FWI_STREAM_ZPML", "1")
-    monkeypatch.setenv("FWI_STREAM_ZPML_REV", "1")
-    test_cpml_vs_oracle(gpu, shape, 8, 8, 30.0, "float32", TOL32, "step3d_stream", {"zchunk": zchunk})
 
 
 @pytest.mark.parametrize("shape", [(40, 36, 44), (60, 52)])
@@ -177,7 +175,7 @@ def test_cpml_absorbs_far_better_than_the_sponge_on_gpu(gpu):
     assert e_sponge > 0.05 and e_cpml < 2e-3
 
 
-def _cpml_vs_c_oracle(w, nt, alpha, kern):
+def _cpml_vs_c_oracle(w, nt, alpha, kern, **kw):
     wav = w.wavelet(np.float64)[:nt]
     p = CPropagator(w.c, w.h, w.dt, w.order, w.npml, abc="cpml", pml_alpha_max=alpha)
     d = p.forward(w.src_idx, wav, w.rec_idx, save=True)
@@ -186,14 +184,14 @@ def _cpml_vs_c_oracle(w, nt, alpha, kern):
     g = p.gradient("velocity")
     p.q_store = None
     with Engine(w.shape, w.h, w.dt, nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max, abc="cpml",
-                pml_alpha_max=alpha) as e:
+                pml_alpha_max=alpha, **kw) as e:
         dg = e.forward(w.c, (w.src_idx, wav), w.rec_idx, save=True)
         assert e.kernel_name == kern
         ag = e.adjoint(r)
         gg = e.gradient("velocity")
     assert rel(dg, d) < TOL32, rel(dg, d)
-    assert rel(ag, a) < 3 * TOL32, rel(ag, a)
-    assert rel(gg, g) < 3 * TOL32, rel(gg, g)
+    assert rel(ag, a) < TOL32, rel(ag, a)
+    assert rel(gg, g) < TOL32, rel(gg, g)
 
 
 def test_cpml_configs1_at_full_size_vs_c_oracle(gpu):
@@ -203,12 +201,16 @@ def test_cpml_configs1_at_full_size_vs_c_oracle(gpu):
     _cpml_vs_c_oracle(workloads.cfg2(1.0), 1000, 3.14159 * 15.0, "step2d_fused")
 
 
-def test_cpml_3d_lines_and_lanes_at_size_vs_c_oracle(gpu):
-    """3-D 160^3 heterogeneous model, npml 16, 400 steps: the x border in step3d_stream's lanes, the z and y borders as
-    line launches (several workgroup tiles, all four z chunks, two segments per line) against the C oracle."""
+@pytest.mark.parametrize("stream_ty,kw", [(None, {}), ("8", {}), ("8", {"update_form": "increment"})])
+def test_cpml_3d_lines_and_lanes_at_size_vs_c_oracle(gpu, monkeypatch, stream_ty, kw):
+    """3-D 160^3 heterogeneous model, npml 16, 400 steps: the x border in step3d_stream's lanes, the z and y borders'
+    term from the line launch (several workgroup tiles, all z chunks, two segments per line) against the C oracle --
+    with the tuned tile shape and with the 8-row tiles of the HBM-regime grids."""
+    if stream_ty:
+        monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
     w = workloads.cfg5(0.625, nshots=1)
     w.npml = 16
-    _cpml_vs_c_oracle(w, 400, 3.14159 * 10.0, "step3d_stream")
+    _cpml_vs_c_oracle(w, 400, 3.14159 * 10.0, "step3d_stream", **kw)
 
 
 @pytest.mark.parametrize("shape,npml", [((130, 250), 16), ((1130, 1070), 40)])
@@ -230,12 +232,15 @@ def test_cpml_fused_launch_is_reproducible_run_to_run(gpu, shape, npml):
         assert np.array_equal(r, runs[0])
 
 
+@pytest.mark.parametrize("stream_ty", [None, "8"])
 @pytest.mark.parametrize("shape,npml,kw", [((96, 72, 128), 16, {}), ((60, 52, 64), 8, {"update_form": "increment"}),
                                            ((41, 37, 50), 9, {"dtype": "float64"})])
-def test_cpml_3d_is_reproducible_run_to_run(gpu, shape, npml, kw):
-    """Lanes + line launches (or slabs + lines): a shot repeated on the same context, with and without the forward-term
+def test_cpml_3d_is_reproducible_run_to_run(gpu, monkeypatch, shape, npml, kw, stream_ty):
+    """Lanes + line launch (or slabs + lines): a shot repeated on the same context, with and without the forward-term
     store, returns the same bits -- the two segments of a line, the two axes and the step kernel never touch a cell at
     the same time."""
+    if stream_ty:
+        monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
     rng = np.random.default_rng(6)
     c = 1900.0 + 800.0 * rng.random(shape)
     h, order, nt = 10.0, 8, 60

@@ -18,7 +18,9 @@ from oracle.c_oracle import CPropagator
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TOL32 = 1e-5   # BASELINE.json north_star: "within 1e-5 relative L2"
+TOL32 = 1e-5   # BASELINE.json north_star: "within 1e-5 relative L2" -- FLAT on seismograms, F^T r and the gradient of a
+               # shared residual since round 4 (a 3x slack on the last two hid a 3-5x regression: profiles/r03_parity.json
+               # measures <= 5.9e-6 on every one of them)
 TOL64 = 1e-10
 FLOOR = 1e-30  # absolute floor of the fuzz comparisons: below fp32's range the oracle's fp64 numbers have no fp32 counterpart
 
@@ -69,8 +71,8 @@ def test_golden(gpu, name, dtype, kernel, tol):
                 dtype=dtype, kernel=kernel)
     assert rel(o["seis"], z["seis"]) < tol
     assert rel(o["adj_src"], z["adj_src"]) < tol
-    assert rel(o["grad_c"], z["grad_c"]) < 3 * tol
-    assert rel(o["grad_m"], z["grad_m"]) < 3 * tol
+    assert rel(o["grad_c"], z["grad_c"]) < tol
+    assert rel(o["grad_m"], z["grad_m"]) < tol
 
 
 # ---------------------------------------------------------------------------
@@ -105,7 +107,18 @@ def test_random_model_vs_oracle(gpu, shape, order, npml, dtype, tol):
     o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r, dtype=dtype)
     assert rel(o["seis"], d) < tol
     assert rel(o["adj_src"], a) < tol
-    assert rel(o["grad_c"], p.gradient()) < 3 * tol
+    assert rel(o["grad_c"], p.gradient()) < tol
+
+
+# The 8-row tile of the 3-D stream kernel (FWI_STREAM_TY=8) is what stream_default_tuning picks for every grid past the
+# Infinity Cache (>= 272^3) -- sizes no oracle finishes in seconds, so every oracle comparison above ran 4-row tiles and
+# the 8-row shape met the oracle only through the translation property (the kernel against itself).  The creation-time
+# hook brings that tile shape to the oracle-sized grids: same bodies, same bar (VERDICT r03 missing #1).
+@pytest.mark.parametrize("shape,order,npml", [c for c in SHAPES if len(c[0]) == 3])
+@pytest.mark.parametrize("dtype,tol", [("float64", TOL64), ("float32", TOL32)])
+def test_random_model_vs_oracle_with_8_row_tiles(gpu, monkeypatch, shape, order, npml, dtype, tol):
+    monkeypatch.setenv("FWI_STREAM_TY", "8")
+    test_random_model_vs_oracle(gpu, shape, order, npml, dtype, tol)
 
 
 @pytest.mark.parametrize("zchunk", [0, 5, 16, 1000])
@@ -144,7 +157,7 @@ def test_stream_kernels_take_any_nx(gpu, shape, dtype, kern, tol):
     a = p.adjoint(r)
     o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r, dtype=dtype, kernel="stream")
     assert o["kernel"].startswith(kern)
-    assert rel(o["seis"], d) < tol and rel(o["adj_src"], a) < tol and rel(o["grad_c"], p.gradient()) < 3 * tol
+    assert rel(o["seis"], d) < tol and rel(o["adj_src"], a) < tol and rel(o["grad_c"], p.gradient()) < tol
 
 
 # ---------------------------------------------------------------------------
@@ -215,9 +228,9 @@ def test_full_size_3d_headline_config_vs_c_oracle(gpu):
     assert rel(dg, d) < TOL32
 
 
-def test_full_size_3d_grid_adjoint_and_gradient_vs_c_oracle(gpu):
+def test_full_size_3d_grid_adjoint_and_gradient_vs_c_oracle(gpu, monkeypatch):
     """The full 256^3 O(8) grid with the sponge, forward(save) + adjoint + gradient against the C oracle on
-    the SAME residual.  400 of the 1000 steps: the oracle's store of the forward term is nt x 128 MiB of host
+    the SAME residual -- with the tuned tile shape (4 rows at this size) and with the 8-row tiles of larger grids.  400 of the 1000 steps: the oracle's store of the forward term is nt x 128 MiB of host
     memory (51 GiB here); the source sits 32 cells under the receiver patch so that the data, the adjoint field
     and their correlation are all well developed within those steps."""
     w = workloads.cfg4(1.0, npml=16)
@@ -231,15 +244,18 @@ def test_full_size_3d_grid_adjoint_and_gradient_vs_c_oracle(gpu):
     a = p.adjoint(r)
     g = p.gradient("velocity")
     p.q_store = None
-    with Engine(w.shape, w.h, w.dt, nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max) as e:
-        dg = e.forward(w.c, (src, wav), w.rec_idx, save=True)
-        assert e.kernel_name == "step3d_stream"
-        ag = e.adjoint(r)
-        gg = e.gradient("velocity")
     assert np.abs(g).max() > 0 and np.abs(a).max() > 0
-    assert rel(dg, d) < TOL32
-    assert rel(ag, a) < 3 * TOL32
-    assert rel(gg, g) < 3 * TOL32
+    for stream_ty in (None, "8"):  # (one oracle run serves both tile shapes)
+        if stream_ty:
+            monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
+        with Engine(w.shape, w.h, w.dt, nt, order=w.order, npml=w.npml, sigma_max=p.sigma_max) as e:
+            dg = e.forward(w.c, (src, wav), w.rec_idx, save=True)
+            assert e.kernel_name == "step3d_stream"
+            ag = e.adjoint(r)
+            gg = e.gradient("velocity")
+        assert rel(dg, d) < TOL32, (stream_ty, rel(dg, d))
+        assert rel(ag, a) < TOL32, (stream_ty, rel(ag, a))
+        assert rel(gg, g) < TOL32, (stream_ty, rel(gg, g))
 
 
 def test_full_size_2d_vs_c_oracle(gpu):
@@ -257,8 +273,8 @@ def test_full_size_2d_vs_c_oracle(gpu):
     o = run_gpu(w.c, w.h, w.dt, w.order, w.npml, p.sigma_max, w.src_idx, wav, w.rec_idx, residual=r)
     assert o["kernel"] == "step2d_fused"
     assert rel(o["seis"], d) < TOL32
-    assert rel(o["adj_src"], a) < 3 * TOL32
-    assert rel(o["grad_c"], g) < 3 * TOL32
+    assert rel(o["adj_src"], a) < TOL32
+    assert rel(o["grad_c"], g) < TOL32
 
 
 @pytest.mark.parametrize("maker,scale,nshots", [(workloads.cfg3, 0.25, 2), (workloads.cfg5, 0.25, 4)])
@@ -502,11 +518,17 @@ def test_increment_form_matches_the_oracle(gpu, shape, order, npml, dtype, tol, 
             assert e.kernel_name == kern
             ag = e.adjoint(r)
             gg = e.gradient()
-        assert rel(dg, d) < tol and rel(ag, a) < 3 * tol and rel(gg, g) < 3 * tol, (K, rel(dg, d), rel(ag, a), rel(gg, g))
+        assert rel(dg, d) < tol and rel(ag, a) < tol and rel(gg, g) < tol, (K, rel(dg, d), rel(ag, a), rel(gg, g))
     if len(shape) == 2:
         with pytest.raises(FwiError):  # the 2-D stream kernels have no increment form: refused, not ignored
             Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, dtype=dtype,
                    update_form="increment", kernel="stream")
+
+
+@pytest.mark.parametrize("shape,order,npml", [((40, 36, 256), 8, 6), ((33, 29, 50), 8, 5), ((30, 28, 36), 4, 0)])
+def test_increment_form_matches_the_oracle_with_8_row_tiles(gpu, monkeypatch, shape, order, npml):
+    monkeypatch.setenv("FWI_STREAM_TY", "8")
+    test_increment_form_matches_the_oracle(gpu, shape, order, npml, "float32", TOL32, "step3d_stream")
 
 
 @pytest.mark.parametrize("shape,order,nt,zc", [
@@ -576,6 +598,14 @@ def test_bf16_forward_term_store(gpu, shape, npml, stride):
             Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=pq.sigma_max, store_dtype="bf16", **bad)
     with pytest.raises(FwiError):
         Engine((40, 40), h, dt, nt, store_dtype="bf16")
+    with pytest.raises(FwiError):  # (round 4: the bf16 store exists for the O(8) stencil only)
+        Engine(shape, h, dt, nt, order=4, npml=npml, store_dtype="bf16")
+
+
+@pytest.mark.parametrize("shape,npml,stride", [((40, 36, 256), 6, 1), ((33, 29, 50), 5, 1), ((33, 29, 50), 0, 3)])
+def test_bf16_forward_term_store_with_8_row_tiles(gpu, monkeypatch, shape, npml, stride):
+    monkeypatch.setenv("FWI_STREAM_TY", "8")
+    test_bf16_forward_term_store(gpu, shape, npml, stride)
 
 
 @pytest.mark.parametrize("shape", [(48, 40, 64), (96, 100)])
@@ -762,7 +792,7 @@ def test_image_stride_matches_the_oracle_definition(gpu, shape, dtype, tol, nt, 
             dg = e.forward(c, (src, w), rec, save=True)
             ag = e.adjoint(r)
             assert rel(dg, d) < tol and rel(ag, a) < tol
-        assert rel(e.gradient(), g_ref) < 3 * tol
+        assert rel(e.gradient(), g_ref) < tol
         assert e.kernel_name == ("step3d_stream" if nd == 3 else "step2d_fused")
 
 
@@ -801,7 +831,7 @@ def test_2d_step_counts_off_the_fused_multiple(gpu, nt):
     a = p.adjoint(r)
     o = run_gpu(c, h, dt, order, npml, p.sigma_max, src, w, rec, r)
     assert o["kernel"] == "step2d_fused"
-    assert rel(o["seis"], d) < TOL32 and rel(o["adj_src"], a) < TOL32 and rel(o["grad_c"], p.gradient()) < 3 * TOL32
+    assert rel(o["seis"], d) < TOL32 and rel(o["adj_src"], a) < TOL32 and rel(o["grad_c"], p.gradient()) < TOL32
 
 
 def test_device_lbfgs_matches_host_lbfgs(gpu):
@@ -1019,7 +1049,7 @@ def fuzz_option_combinations(seed, ncases, setenv, maxdim=37):
         abc = str(rng.choice(["sponge", "cpml"]))
         alpha = float(rng.choice([0.0, 25.0])) if abc == "cpml" else 0.0
         form = str(rng.choice(["standard", "increment"]))
-        bf16 = nd == 3 and form == "standard" and (abc == "sponge" or npml == 0) and rng.random() < 0.4
+        bf16 = nd == 3 and order == 8 and form == "standard" and (abc == "sponge" or npml == 0) and rng.random() < 0.4
         ck = int(rng.choice([0, 0, 5])) if not bf16 else 0
         pair = nd == 3 and rng.random() < 0.5
         stride = int(rng.choice([1, 1, 3])) if ck == 0 else 1
