@@ -78,9 +78,9 @@ def cpu_baseline(w, sample_steps):
 
 def measured_traffic(leg):
     """Fabric-side bytes per launch of `leg`'s dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r03_traffic.json, else r02_traffic.json, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
+    (profiles/r04_traffic.json, else r03 / r02, written by tools/summarize_profile.py from separate --pmc FETCH_SIZE /
     WRITE_SIZE runs of `bench.py --leg <leg>`), or None.  PMC counters cannot be collected in-process."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ent = json.load(open(path)).get(leg)
@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--mode", default="forward", choices=["forward", "gradient"],
                     help="headline leg: forward = the stencil run; gradient = forward(save) + adjoint(imaging) per step")
     ap.add_argument("--leg", default="all", choices=["all", "headline", "hbm", "gradient", "gradient_increment", "cfg2",
-                                                     "cfg2_cpml", "cpml3d", "fp64", "point", "bf16"],
+                                                     "cfg2_cpml", "cpml3d", "cpml3d_adjoint", "cpml512", "fp64", "point", "bf16"],
                     help="all: headline + (at N = 1) the three extra legs; or one leg alone (profiling passes)")
     ap.add_argument("--leg-nt", type=int, default=0, help="time steps of a --leg run (0 = the leg's own)")
     ap.add_argument("--cpu-steps", type=int, default=200,
@@ -414,10 +414,11 @@ def main():
                            "256^3 forward with the CONVOLUTIONAL PML, npml %d: fields + 50 MB of memory variables = 271 "
                            "MB, and every byte a step touches counts against the Infinity Cache's 256 MiB (streaming "
                            "hints do not exempt it), so this is an HBM-regime run: algorithmic 369 MB at the ~5.5 TB/s "
-                           "the 512^3 run sustains = 67 us is the floor of a fully fused step.  One time step = the step "
-                           "kernel with the x border's recursion in its lanes + ONE line launch each for the z and the y "
-                           "border (fwi_pml.hip pml_line: they re-read u, C and read-modify-write u' of their border, ~"
-                           "78 MB each by the code's byte count, 99 by the counters: that is where the distance to the floor is); `kernel_avg_us` is the whole "
+                           "the 512^3 run sustains = 67 us is the floor of a fully fused step.  One time step = ONE line "
+                           "launch (fwi_pml.hip pml_line_t: the z and y borders' recursions, which hand their term over in "
+                           "arrays compact over the border shells) + the step kernel with the x border's recursion in its "
+                           "lanes, which adds the handed-over terms inside q (round 4; round 3: the step kernel + one line "
+                           "launch per axis that re-read u, C and read-modified-wrote u'); `kernel_avg_us` is the whole "
                            "step" % w.npml,
                            extra_bytes=mv)
         r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
@@ -425,6 +426,36 @@ def main():
         r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
         r["kernel"] = info["kernel"]
         legs["cpml3d"] = r
+    # measurement-only CPML legs (profiles/r04_*; never part of the default line): the gradient sweeps at 256^3 and the
+    # forward sweep at 512^3, where stream_default_tuning picks the 8-row tiles
+    if args.leg == "cpml3d_adjoint":
+        def wl():
+            w = workloads.cfg4(1.0, npml=16)
+            w.nt = args.leg_nt or 300
+            return w
+        w, el, step_us, info = run_leg(wl, local, 2, 1, grad=True, engine_kw=dict(abc="cpml", pml_alpha_max=np.pi * 10.0))
+        mv = 16 * 3 * (2 * w.npml * w.shape[0] * w.shape[1])
+        r = roofline_entry("cpml3d_adjoint", w, step_us, 22.0, "hbm",
+                           "256^3 / npml %d gradient shot with the CPML: forward + store (20 B/update) and adjoint + paired "
+                           "imaging (24 B/update), one line launch + one step launch per time step either way" % w.npml,
+                           extra_bytes=mv)
+        r["us_per_time_step_both_sweeps_mean"] = round(step_us, 3)
+        r["kernel"] = info["kernel"]
+        legs["cpml3d_adjoint"] = r
+    if args.leg == "cpml512":
+        def wl():
+            w = workloads.cfg4(2.0, npml=16)
+            w.nt = args.leg_nt or 60
+            return w
+        w, el, step_us, info = run_leg(wl, local, 2, 1, engine_kw=dict(abc="cpml", pml_alpha_max=np.pi * 10.0))
+        mv = 16 * 3 * (2 * w.npml * w.shape[0] * w.shape[1])
+        r = roofline_entry("cpml512", w, step_us, BYTES_PER_UPDATE, "hbm",
+                           "512^3 forward with the CPML, npml %d: 8-row tiles (two waves per SIMD, 256 registers: the x "
+                           "border's variants fit since round 4, no scratch)" % w.npml, extra_bytes=mv)
+        r["us_per_time_step"] = round(step_us, 3)
+        r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
+        r["kernel"] = info["kernel"]
+        legs["cpml512"] = r
     for name, kw, bpu, what in (("fp64", dict(dtype="float64"), 32, "fp64 engine (step3d_stream<double>, 32 B/update)"),
                                 ("point", dict(kernel="point"), 16, "generic one-thread-per-point kernel (step_point)"),
                                 ("bf16", dict(store_dtype="bf16"), None, "bf16 forward-term store")):

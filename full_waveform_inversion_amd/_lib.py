@@ -15,13 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FWI_HIP_LIB") or os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
 UPDATE_FORMS = {"standard": 0, "increment": 1}
 ABCS = {"sponge": 0, "cpml": 1}
 STORE_DTYPES = {"native": 0, "bf16": 1}
+LAUNCH_MODES = {"auto": 0, "stream": 1, "graph": 2}
 UNIQUE_ID_BYTES = 128
 ERROR_NAMES = {1: "FWI_EINVAL", 2: "FWI_EHIP", 3: "FWI_ESTATE", 4: "FWI_ENOMEM", 5: "FWI_ECOMM"}
 
@@ -40,7 +41,7 @@ class Config(C.Structure):
                 ("npml", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
                 ("kernel", C.c_int32), ("zchunk", C.c_int32), ("ckpt_interval", C.c_int32),
                 ("image_stride", C.c_int32), ("update_form", C.c_int32), ("abc", C.c_int32),
-                ("store_dtype", C.c_int32), ("reserved0", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
+                ("store_dtype", C.c_int32), ("launch_mode", C.c_int32), ("h", C.c_double), ("dt", C.c_double),
                 ("sigma_max", C.c_double), ("pml_alpha_max", C.c_double)]
 
 
@@ -68,7 +69,9 @@ SIGNATURES = {
     "fwi_comm_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "fwi_comm_abort": (C.c_int, [_P]),
     "fwi_last_loop_ms": (C.c_int, [_P, C.POINTER(_D)]),
+    "fwi_last_host_ms": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D)]),
     "fwi_synchronize": (C.c_int, [_P]),
+    "fwi_check_padding": (C.c_int, [_P, C.POINTER(_I64)]),
     "fwi_kernel_name": (C.c_char_p, [_P]),
     "fwi_device_count": (C.c_int, [C.POINTER(_I32)]),
     "fwi_vec_create": (C.c_int, [_P, _I32]),

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -53,6 +54,13 @@ struct fwi_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_loop_time = false;
+    // FWI_LAUNCH_GRAPH: the time loop of a sweep is captured and launched as one hipGraph.  The executable graph of
+    // the last sweep is kept until the next sweep (or destroy) replaces it -- it may still be running when the call
+    // that launched it returns its samples.
+    bool graph_mode = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    double host_submit_ms = 0.0, host_graph_ms = 0.0;
 
     // device fields
     void *u[2] = {nullptr, nullptr};  // padded wavefields (ping-pong)
@@ -243,6 +251,60 @@ int ensure(fwi_ctx *ctx, void **p, size_t *cap, size_t bytes) {
     *cap = bytes;
     return FWI_OK;
 }
+
+// The time loop of one sweep, either submitted launch by launch or captured into a hipGraph and launched once
+// (fwi_config.launch_mode).  begin() stands where the loop's first launch is about to be formed, end() behind its
+// last one; between them only kernel launches and device-to-device copies on ctx->stream may happen (true of
+// run_steps / run_fused / run_pairs, the checkpoint copies and the record / imaging tails).  A TimeLoop that goes out
+// of scope inside a capture (an error return) ends the capture and drops the partial graph.
+struct TimeLoop {
+    fwi_ctx *ctx;
+    bool capturing = false;
+    std::chrono::steady_clock::time_point t0;
+    explicit TimeLoop(fwi_ctx *c) : ctx(c) {}
+    int begin() {
+        t0 = std::chrono::steady_clock::now();
+        ctx->host_graph_ms = 0.0;
+        if (ctx->graph_exec) {  // the previous sweep's graph: finished by now or not, the stream orders us behind it
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipGraphExecDestroy(ctx->graph_exec);
+            ctx->graph_exec = nullptr;
+        }
+        if (ctx->graph) {
+            (void)hipGraphDestroy(ctx->graph);
+            ctx->graph = nullptr;
+        }
+        if (ctx->graph_mode) {
+            HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            capturing = true;
+        } else {
+            HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        }
+        return FWI_OK;
+    }
+    int end() {
+        if (capturing) {
+            capturing = false;
+            HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &ctx->graph));
+            HIPCHK(ctx, hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
+            ctx->host_graph_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            HIPCHK(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->have_loop_time = true;
+        return FWI_OK;
+    }
+    ~TimeLoop() {
+        if (capturing) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(ctx->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+        }
+    }
+};
 
 // Translate (n, ndim) int32 grid indices into padded / compact flat indices.
 int flatten(fwi_ctx *ctx, const int32_t *idx, int n, std::vector<int64_t> &pidx,
@@ -1086,7 +1148,8 @@ struct Impl {
         // odd count goes through the single-step kernel)
         const int npair = (ctx->pair3d && !save && base_args(ctx, 0).damp == 0) ? (nt & ~1) : 0;
         if ((fused || nfused || npair) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        TimeLoop loop(ctx);
+        if ((rc = loop.begin())) return rc;
         if (npair) {
             if ((rc = run_pairs(ctx, sw, spare, 0, npair, ctx->src, (const T *)ctx->wav, &ctx->rec, series, T(1))))
                 return rc;
@@ -1126,8 +1189,7 @@ struct Impl {
                 return rc;
         }
         if ((rc = flush_record(ctx, sw, ctx->rec, series, T(1)))) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
-        ctx->have_loop_time = true;
+        if ((rc = loop.end())) return rc;
         if (fused || nfused || npair) {  // the buffer pairs may have changed roles: keep ownership consistent
             ctx->u[0] = sw.f[0];
             ctx->u[1] = sw.f[1];
@@ -1166,7 +1228,12 @@ struct Impl {
         const T *amp = (const T *)ctx->amp;
         auto none = [](int) -> T * { return nullptr; };
         auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
-        HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+        const bool fused = use_fused(ctx, nt);
+        const int nfused = mixed_fused_steps(ctx, nt);
+        void *spare[2] = {ctx->fx[0], ctx->fx[1]};
+        if ((fused || nfused) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
+        TimeLoop loop(ctx);
+        if ((rc = loop.begin())) return rc;
         const T *q0 = nullptr;  // q^0, for the last pairing (mu^1 with q^0)
         // Lagged imaging: adjoint step n (which reads mu^{n+2} as u_cur and mu^{n+3} as u_prev) owns
         // the pairing P(n) = (mu^{n+2}, q^{n+1}).  Steps are taken in pairs: P(n+1) is deferred and
@@ -1191,10 +1258,6 @@ struct Impl {
                 }
             }
         };
-        const bool fused = use_fused(ctx, nt);
-        const int nfused = mixed_fused_steps(ctx, nt);
-        void *spare[2] = {ctx->fx[0], ctx->fx[1]};
-        if ((fused || nfused) && (rc = zero_fields(ctx, spare[0], spare[1]))) return rc;
         bool imaged_all = false;  // the fused kernel pairs mu^{n+1} with q^n inside the launch (no lag)
         if (fused && image && K > 0) {
             // checkpointed, fused: recompute each segment's forward storing q into the slot buffer,
@@ -1310,8 +1373,7 @@ struct Impl {
             HIPCHK(ctx, launch_source_image<T>((const T *)ctx->series, (const T *)ctx->wav, (const int64_t *)ctx->src.cidx,
                                                (const T *)ctx->src.cq, (T *)ctx->g_acc, nt, ctx->nsrc, ctx->istride,
                                                (T)(1.0 / (double)rs), s));
-        HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
-        ctx->have_loop_time = true;
+        if ((rc = loop.end())) return rc;
         return download_samples(ctx, (adj_src_out && ctx->nsrc) ? adj_src_out : nullptr, ctx->series, nt, ctx->nsrc,
                                 ctx->src_sp, nullptr, nullptr);
     }
@@ -1560,7 +1622,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (cfg->abc != FWI_ABC_SPONGE && cfg->abc != FWI_ABC_CPML) return bad("unknown abc");
     if (cfg->store_dtype != FWI_STORE_NATIVE && cfg->store_dtype != FWI_STORE_BF16) return bad("unknown store_dtype");
     if (cfg->store_dtype == FWI_STORE_BF16 && cfg->dtype != FWI_F32) return bad("store_dtype bf16 needs an fp32 context");
-    if (cfg->reserved0 != 0) return bad("reserved0 must be 0");
+    if (cfg->launch_mode < FWI_LAUNCH_AUTO || cfg->launch_mode > FWI_LAUNCH_GRAPH) return bad("unknown launch_mode");
     if (!(cfg->pml_alpha_max >= 0)) return bad("pml_alpha_max must be >= 0");
     if (cfg->store_dtype == FWI_STORE_BF16 &&
         (cfg->ndim != 3 || cfg->order != 8 || cfg->kernel == FWI_KERNEL_POINT || cfg->ckpt_interval > 0 ||
@@ -1580,13 +1642,16 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         return FWI_ENOMEM;
     }
     ctx->cfg = *cfg;
-    ctx->gd = make_grid(cfg->ndim, cfg->nz, cfg->ny, cfg->nx, cfg->order);
+    // (FWI_XPITCH_EXTRA: the layout A/B hook of DESIGN.md's pitch sweep, read ONCE per process -- not on any hot path)
+    static const int xpitch_extra = getenv("FWI_XPITCH_EXTRA") ? atoi(getenv("FWI_XPITCH_EXTRA")) : 0;
+    ctx->gd = make_grid(cfg->ndim, cfg->nz, cfg->ny, cfg->nx, cfg->order, xpitch_extra);
     ctx->esize = cfg->dtype == FWI_F32 ? 4 : 8;
     ctx->ckpt = cfg->ckpt_interval;
     ctx->istride = cfg->image_stride > 1 ? cfg->image_stride : 1;
     ctx->inc = cfg->update_form == FWI_UPDATE_INCREMENT;
     ctx->cpml = cfg->abc == FWI_ABC_CPML && cfg->npml > 0;
     ctx->qbf16 = cfg->store_dtype == FWI_STORE_BF16;
+    ctx->graph_mode = cfg->launch_mode == FWI_LAUNCH_GRAPH;  // (AUTO is resolved below, once the launch plan is known)
     ctx->qes = ctx->qbf16 ? 2 : (cfg->dtype == FWI_F32 ? 4 : 8);
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
@@ -1646,6 +1711,12 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (ctx->cpml && cfg->ndim == 3) ctx->pml_lines = pml_line_axes(ctx->gd, cfg->npml);
     ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && ctx->pml_lines == 3 && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
+    // launch_mode AUTO: a hipGraph for time loops that alternate between different kernels within a step (measured on
+    // the 3-D CPML, 256^3 / npml 16: forward 91.2 -> 85.6, store 100.7 -> 87.9, adjoint 110.5 -> 106.7 us/step; the graph's
+    // capture + instantiation costs the host what the stream submission did, ~2.3 us per launch); loops of ONE kernel
+    // (2-D fused at 256^2 ... 1024^2 with or without the CPML inside, the plain 3-D step loop) run the same either way
+    // (+-0.7 %, profiles/r04_graph_probe.jsonl) and keep the stream.
+    if (cfg->launch_mode == FWI_LAUNCH_AUTO) ctx->graph_mode = ctx->cpml && !ctx->fused2d;
     if (getenv("FWI_DEBUG_PML"))
         fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d line-axes=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
                 (int)ctx->fused2d, (int)ctx->xpml, ctx->pml_lines, ctx->tune.ty, ctx->tune.zchunk);
@@ -1674,6 +1745,8 @@ void fwi_destroy(fwi_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     void *ptrs[] = {ctx->u[0], ctx->u[1], ctx->C, ctx->c_dev, ctx->dz, ctx->dy, ctx->dx, ctx->q_store,
                     ctx->g_acc, ctx->g_out, ctx->red, ctx->amp, ctx->series, ctx->wav, ctx->snap, ctx->fwd[0],
@@ -2064,6 +2137,32 @@ int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_out = ms;
+    return FWI_OK;
+}
+
+int fwi_check_padding(fwi_ctx *ctx, int64_t *dirty_out) {
+    if (!ctx || !dirty_out) return FWI_EINVAL;
+    (void)hipSetDevice(ctx->cfg.device);
+    unsigned long long *cnt = (unsigned long long *)(ctx->red + 6);
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), ctx->stream));
+    for (void *f : {ctx->u[0], ctx->u[1], ctx->C, ctx->vf, ctx->fwv, ctx->fx[0], ctx->fx[1], ctx->fwd[0], ctx->fwd[1],
+                    ctx->fwx[0], ctx->fwx[1]}) {
+        if (!f) continue;
+        HIPCHK(ctx, DISPATCH(ctx, launch_count_dirty_padding<float>(ctx->gd, (const float *)f, cnt, ctx->stream),
+                             launch_count_dirty_padding<double>(ctx->gd, (const double *)f, cnt, ctx->stream)));
+    }
+    unsigned long long n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, cnt, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *dirty_out = (int64_t)n;
+    return FWI_OK;
+}
+
+int fwi_last_host_ms(fwi_ctx *ctx, double *submit_ms_out, double *graph_build_ms_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (!ctx->have_loop_time) return ctx->fail(FWI_ESTATE, "fwi_last_host_ms: no time loop has run");
+    if (submit_ms_out) *submit_ms_out = ctx->host_submit_ms;
+    if (graph_build_ms_out) *graph_build_ms_out = ctx->host_graph_ms;
     return FWI_OK;
 }
 

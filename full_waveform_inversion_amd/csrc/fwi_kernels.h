@@ -32,7 +32,12 @@ struct GridDesc {
     int64_t npts;    // nz * ny * cx: elements of one compact array (pad columns included)
 };
 
-GridDesc make_grid(int ndim, int nz, int ny, int nx, int order);
+// `xpitch_extra`: floats of slack added to the (tight) x pitch -- the A/B hook behind DESIGN.md's pitch sweep; fwi_create
+// reads FWI_XPITCH_EXTRA once per process and passes it here (it is not consulted on any other path).
+GridDesc make_grid(int ndim, int nz, int ny, int nx, int order, int xpitch_extra = 0);
+// Widest x tile of any step kernel in elements (64 lanes x one float4): the tail behind the last row of a padded field
+// covers the edge loads of such a tile whose row ends early (values never used).
+constexpr int MAX_TILE_X = 256;
 
 template <typename T>
 struct StepArgs {
@@ -139,6 +144,11 @@ hipError_t launch_repack(const GridDesc &g, T *dst, const T *src, int to_compact
 // Cpad (padded, halo untouched) = dt2 * c^2 from the compact velocity c; *bad += #invalid entries
 template <typename T>
 hipError_t launch_build_model(const GridDesc &g, const T *c, T *Cpad, double dt2, int *bad, hipStream_t s);
+// *bad += the number of cells of the padded field `f` OUTSIDE the grid's interior (halo planes / rows, the shared x halo
+// between rows, the look-ahead planes and the tail) that are not exactly zero.  The tight row pitch rests on nothing ever
+// writing there (make_grid); tests/test_gpu_round4.py checks it after every kind of sweep.
+template <typename T>
+hipError_t launch_count_dirty_padding(const GridDesc &g, const T *f, unsigned long long *bad, hipStream_t s);
 // *out += sum a[i] * b[i]  (out must be zeroed by the caller)
 template <typename T>
 hipError_t launch_dot(const T *a, const T *b, int64_t n, double *out, hipStream_t s);

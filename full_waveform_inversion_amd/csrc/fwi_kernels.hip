@@ -16,7 +16,7 @@
 
 namespace fwi {
 
-GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
+GridDesc make_grid(int ndim, int nz, int ny, int nx, int order, int xpitch_extra) {
     GridDesc g;
     g.ndim = ndim;
     g.nz = nz;
@@ -31,9 +31,8 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     // Gpts/s, 448^3 299 -> 351, 640^3 293 -> 333, 320^3 266 -> 325, 272^3 277 -> 339, 384^3 289 -> 323).  Pitch sweep at 512^3,
     // nx + 8 / 16 / 24 / 32 / 64 / 128 / 256 floats: 350 / 340 / 317 / 305 / 292 / 287 / 276 Gpts/s; nx + 4 against nx + 8: 256^3
     // 424 -> 434, 384^3 301 -> 305.  2-D (cache-resident up to ~4096^2): +1..2 % at every size from 1000^2 to 8192^2.
-    // FWI_XPITCH_EXTRA (floats) is the A/B hook.
-    g.sy = HALO + round_up(nx, XALIGN);
-    if (const char *e = getenv("FWI_XPITCH_EXTRA")) g.sy += std::max(0, atoi(e) / 4 * 4);
+    // `xpitch_extra` (FWI_XPITCH_EXTRA floats, read once by fwi_create) is the A/B hook.
+    g.sy = HALO + round_up(nx, XALIGN) + std::max(0, xpitch_extra / 4 * 4);
     // (rows whose interior starts on a 128-byte line -- pitch nx + 32 with the gap shared as right / left halo -- were
     // measured as well: 256^3 +2 %, 512^3 +1 %, 640^3 -8 %: not adopted)
     // (sharing the y-halo rows between consecutive planes the same way was measured: within noise, 512^3 349 vs 352)
@@ -43,7 +42,7 @@ GridDesc make_grid(int ndim, int nz, int ny, int nx, int order) {
     // 2-D: rows are the tiled axis of step2d_tile, so they are rounded like y is in 3-D.
     // 3-D: LOOKAHEAD extra zero planes behind the far z halo, so the stream kernel's prefetches of
     // planes z + r + 1 ... need no clamping (affine addresses: the plane offsets strength-reduce).
-    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO) + HALO + 2 * 256;  // (+ the last row's right halo, and
+    g.ptot = g.sz * (int64_t)(((ndim == 2) ? round_up(nz, YALIGN) : nz + LOOKAHEAD) + 2 * HALO) + HALO + 2 * MAX_TILE_X;  // (+ the last row's right halo, and
                                         // the edge loads of a 256-column tile whose row ends early: values never used)
     g.cx = (int)round_up(nx, 4);
     g.npts = (int64_t)nz * g.ny * g.cx;
@@ -608,6 +607,31 @@ hipError_t launch_repack(const GridDesc &g, T *dst, const T *src, int to_compact
     return hipGetLastError();
 }
 
+// cells of a padded field outside the interior that are not exactly zero (NaN counts)
+template <typename T>
+__global__ void dirty_padding_kernel(GridDesc g, const T *f, unsigned long long *bad) {
+    const int hy = g.ndim == 3 ? HALO : 0;
+    unsigned long long n = 0;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < g.ptot; p += (int64_t)gridDim.x * blockDim.x) {
+        // interior cell (z, y, x) lives at off0 + z sz + y sy + x with off0 = HALO sz + hy sy + HALO: shift by the x halo
+        const int64_t q = p - HALO;
+        bool interior = false;
+        if (q >= 0) {
+            const int64_t zz = q / g.sz, r = q - zz * g.sz, yy = r / g.sy, xx = r - yy * g.sy;
+            interior = zz >= HALO && zz < HALO + g.nz && yy >= hy && yy < hy + g.ny && xx < g.nx;
+        }
+        if (!interior && !(f[p] == T(0))) ++n;
+    }
+    if (n) atomicAdd(bad, n);
+}
+
+template <typename T>
+hipError_t launch_count_dirty_padding(const GridDesc &g, const T *f, unsigned long long *bad, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (g.ptot + 255) / 256));
+    hipLaunchKernelGGL(dirty_padding_kernel<T>, dim3(blocks), dim3(256), 0, s, g, f, bad);
+    return hipGetLastError();
+}
+
 // wave64 shuffle reduction -> LDS across the 4 waves -> one fp64 atomic per block
 template <typename T>
 __global__ __launch_bounds__(256) void dot_kernel(const T *a, const T *b, int64_t n, double *out) {
@@ -767,6 +791,7 @@ hipError_t launch_absmax(const T *x, int64_t n, double *out, hipStream_t s) {
                                                     hipStream_t);                                  \
     template hipError_t launch_repack<T>(const GridDesc &, T *, const T *, int, hipStream_t);       \
     template hipError_t launch_dot<T>(const T *, const T *, int64_t, double *, hipStream_t);         \
+    template hipError_t launch_count_dirty_padding<T>(const GridDesc &, const T *, unsigned long long *, hipStream_t); \
     template hipError_t launch_residual_l2<T>(const T *, T *, int64_t, double *, hipStream_t);       \
     template hipError_t launch_scatter_series<T>(const T *, T *, const int *, const T *, int, int, int, hipStream_t); \
     template hipError_t launch_gather_series<T>(const T *, T *, const int *, const T *, int, int, int, hipStream_t);  \

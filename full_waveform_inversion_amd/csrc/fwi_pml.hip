@@ -686,9 +686,8 @@ int pml_line_axes(const GridDesc &g, int npml) {
 
 // 8-byte lanes for fp32, 16-byte for fp64 (256^3 / npml 16 forward, us/step: 4-byte lanes 103-106, 8-byte 99-101,
 // 16-byte 110: measured on the round-3 form).
-template <typename T, int R, bool REV>
-static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
-    constexpr int VL = 2;
+template <typename T, int R, bool REV, int VL>
+static void launch_pml_line_vl(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
     const int nxv = g.cx / VL;
     const int bx = nxv <= 16 ? 16 : nxv <= 32 ? 32 : 64, by = 256 / bx;
     const int gx = (nxv + bx - 1) / bx;
@@ -697,6 +696,15 @@ static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStrea
     const int nby = (axes & 2) ? gx * goy * (g.ny < 2 * p.npml + 3 * R ? 1 : 2) : 0;
     if (nbz + nby == 0) return;
     hipLaunchKernelGGL((pml_line_t<T, R, REV, VL>), dim3(nbz + nby), dim3(bx, by), 0, s, p, g, gx, goz, nbz, goy);
+}
+
+template <typename T, int R, bool REV>
+static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
+    if constexpr (std::is_same<T, float>::value && R == 4) {
+        static const bool wide = getenv("FWI_PML_LINE_VL") && atoi(getenv("FWI_PML_LINE_VL")) == 4;  // A/B hook
+        if (wide) return launch_pml_line_vl<T, R, REV, 4>(g, p, s, axes);
+    }
+    launch_pml_line_vl<T, R, REV, 2>(g, p, s, axes);
 }
 
 template <typename T, int R>

@@ -46,15 +46,20 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     // stores its memory variables cell by cell (the slab row holds the other side's cells right behind)
     constexpr int XP = XPM == 0 ? 0 : ((XPM - 1) & 1) + 1;
     constexpr bool XMASK = XPM > 2;
-    // LATE: 8-row tiles are 512 threads = two waves per SIMD = 256 registers per lane, which the x border's recursion
+    // DIET: 8-row tiles are 512 threads = two waves per SIMD = 256 registers per lane, which the x border's recursion
     // (its operands, windows and the handed-over terms on top of the queues) does not fit with rings of PF + 1 slots:
     // round 3 shipped its adjoint variants with 10 - 38 spilled registers, i.e. scratch reloads in the pipelined loop.
-    // Those variants now keep ONE slot per pointwise operand (u_prev / v, C, the x border's memory variables, the
-    // handed-over terms) and issue the load of plane z + 1 right AFTER the last use of plane z's value -- the load still
-    // has a whole iteration to land -- fetch the halo rows one plane ahead instead of r, and keep the lane's a(x), b(x)
-    // in LDS instead of registers: 44 registers less, no scratch (tests/test_code_objects.py).
-    constexpr bool LATE = TY == 8 && XP != 0;
-    static_assert(!LATE || PF == 1, "the single-slot rings are written for a prefetch distance of one plane");
+    // Each variant now takes as much of the following as it needs to fit (tests/test_code_objects.py: no scratch) and
+    // no more -- every item costs a little of the loop's memory-level parallelism (512^3 forward with everything on:
+    // 554 -> 607 us/step, measured):
+    //   1  the lane's a(x), b(x) live in LDS instead of registers (-8)                       [forward sweeps]
+    //   2  + the handed-over terms keep ONE slot: the load of plane z + 1 is issued right after the last use of plane
+    //        z's value -- it still has most of an iteration to land (-8)                     [adjoint, no imaging]
+    //   3  + the same for u_prev / v, C and the x border's memory variables (-16), and the halo rows are fetched one
+    //        plane ahead instead of r (-12)                                                 [adjoint + imaging]
+    constexpr int DIET = (TY == 8 && XP != 0) ? (XP == 2 ? (IMAGE ? 3 : 2) : 1) : 0;
+    constexpr bool XC_LDS = DIET >= 1, LATE_T = DIET >= 2, LATE = DIET >= 3;
+    static_assert(DIET < 2 || PF == 1, "the single-slot rings are written for a prefetch distance of one plane");
     constexpr int NH = (2 * R + TY - 1) / TY;  // halo rows each wave fetches per plane
     constexpr int TRASH = TY + 2 * R;          // LDS row that absorbs the writes of idle slots
     constexpr int LROWS = TY + 2 * R + 1;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     // x-border CPML in the lanes: a(x), b(x) of this lane's cells (0 off the border, so that psi and zeta vanish
     // there whatever was loaded), the lane's offset in a row of the memory-variable arrays (nz, ny, 2 npml)
     V xca, xcb;
-    __shared__ V xcl[LATE ? 2 : 1][LATE ? TY : 1][LATE ? 64 : 1];  // (LATE: the lane's a(x), b(x), read back per plane)
+    __shared__ V xcl[XC_LDS ? 2 : 1][XC_LDS ? TY : 1][XC_LDS ? 64 : 1];  // (DIET: the lane's a(x), b(x), read back per plane)
     unsigned xld = 0;
     bool xin = false;
     unsigned xcells = 0;  // (XMASK) which of the lane's cells are border cells
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             in |= b;
             xcells |= b ? 1u << j : 0u;
         }
-        if constexpr (LATE) {  // (each thread reads its own slots only: no barrier)
+        if constexpr (XC_LDS) {  // (each thread reads its own slots only: no barrier)
             xcl[0][ty][lane] = xca;
             xcl[1][ty][lane] = xcb;
         }
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     for (int k = 0; k < 2 * R + PF; ++k) zq[k] = ldv<T>(a.u_cur + (int64_t)(z0 - R + k) * sz + poff);
     V up[NRP], Cc[NRP], halo[NRH][NH];
     V xps[XP ? NRP : 1], xzt[XP ? NRP : 1];  // psi / zeta (adjoint: pt / zt) of the x border, fetched like up / Cc
-    V tzr[TP ? NRP : 1], tyr[TP ? NRP : 1];  // the handed-over z / y border terms of the planes in flight
+    constexpr int NRT = LATE_T ? 1 : NR;
+    V tzr[TP ? NRT : 1], tyr[TP ? NRT : 1];  // the handed-over z / y border terms of the planes in flight
     // y shell: fixed per thread.  Rows off the shell (and lanes that own no points) re-read the array's first vectors.
     bool yin = false;
     unsigned tyoff = 0;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             // the pointwise operands of plane z + PF (LATE: into the one slot, once plane z's values have been used)
             // (plain loads: non-temporal hints on these read-once streams were measured and
             // rejected -- 256^3 39 -> 51 us/step, they defeat Infinity-Cache residency; 512^3 +-2 %)
-            const int cp = LATE ? 0 : cur, np = LATE ? 0 : nxt;
+            const int cp = LATE ? 0 : cur, np = LATE ? 0 : nxt, ct = LATE_T ? 0 : cur, nt_ = LATE_T ? 0 : nxt;
             auto fetch_pointwise = [&]() __attribute__((always_inline)) {
                 up[np] = ldv<T>(pw + on + poff);
                 Cc[np] = ldv<T>(a.C + on + poff);
@@ -279,12 +285,15 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     xps[np] = ldv<T>(a.xp_psi + ox);
                     xzt[np] = ldv<T>(a.xp_zeta + ox);
                 }
+            };
+            auto fetch_terms = [&]() __attribute__((always_inline)) {
                 if constexpr (TP) {
-                    tzr[np] = tz_at(z + PF);
-                    tyr[np] = ty_at(z + PF);
+                    tzr[nt_] = tz_at(z + PF);
+                    tyr[nt_] = ty_at(z + PF);
                 }
             };
             if constexpr (!LATE) fetch_pointwise();
+            if constexpr (!LATE_T) fetch_terms();
             V qi, qi2, gi;
             if (IMAGE) {
                 const unsigned co = act ? coff : 0u;
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                     }
                 };
                 const V m0 = xps[cp], m1 = xzt[cp];
-                if constexpr (LATE) {
+                if constexpr (XC_LDS) {
                     // an index the compiler cannot see through: otherwise it hoists these loop-invariant reads out of the
                     // z loop and the eight registers are back
                     int opq = 0;
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             for (int j = 0; j < VL; ++j) {
                 T br = lap.v[j];  // the bracket of q: L u + the CPML terms of the three axes
                 if (XP) br += xterm.v[j];
-                if (TP) br += (zin ? tzr[cp].v[j] : T(0)) + (yin ? tyr[cp].v[j] : T(0));
+                if (TP) br += (zin ? tzr[ct].v[j] : T(0)) + (yin ? tyr[ct].v[j] : T(0));
                 q.v[j] = Cc[cp].v[j] * br;
                 if (INC) {  // v' = A (B v + q), u' = u + v'
                     vn.v[j] = DAMP ? fma(B.v[j], up[cp].v[j], q.v[j]) * A.v[j] : up[cp].v[j] + q.v[j];
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
                 }
             }
             if constexpr (LATE) fetch_pointwise();  // (every use of plane z's pointwise operands lies above)
+            if constexpr (LATE_T) fetch_terms();
             if (act) {
                 if (INC) stv<T>(a.v + (int64_t)z * sz + poff, vn);
                 stv<T>(a.u_prev + (int64_t)z * sz + poff, un);

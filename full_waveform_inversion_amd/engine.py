@@ -50,7 +50,7 @@ class Engine:
 
     def __init__(self, shape, h, dt, nt_max, order=8, npml=0, sigma_max=None, dtype="float32",
                  device=0, kernel="auto", zchunk=0, ckpt_interval=0, image_stride=1, update_form="standard",
-                 abc="sponge", pml_alpha_max=0.0, store_dtype="native"):
+                 abc="sponge", pml_alpha_max=0.0, store_dtype="native", launch_mode="auto"):
         shape = tuple(int(s) for s in shape)
         if len(shape) not in (2, 3):
             raise ValueError("shape must be (nz, nx) or (nz, ny, nx)")
@@ -68,8 +68,11 @@ class Engine:
         self._ckpt = int(ckpt_interval)
         self._istride = int(image_stride)
         self._update_form = _lib.UPDATE_FORMS[update_form]
+        self.update_form = update_form
         self._abc = _lib.ABCS[abc]
         self._store_dtype = _lib.STORE_DTYPES[store_dtype]
+        # "graph": each sweep's time loop as one hipGraph; "auto": where that was measured to pay (fwi_config.launch_mode)
+        self._launch_mode = _lib.LAUNCH_MODES[launch_mode]
         self.pml_alpha_max = float(pml_alpha_max)
         self._lib = _lib.load()
         self._ctx = None
@@ -87,7 +90,8 @@ class Engine:
                           self.npml, self.device,
                           _lib.F32 if self.dtype == np.float32 else _lib.F64, self._kernel,
                           self._zchunk, self._ckpt, self._istride, self._update_form, self._abc,
-                          self._store_dtype, 0, self.h, self.dt, float(self.sigma_max), self.pml_alpha_max)
+                          self._store_dtype, self._launch_mode, self.h, self.dt, float(self.sigma_max),
+                          self.pml_alpha_max)
         ctx = C.c_void_p()
         _lib.check(None, self._lib.fwi_create(C.byref(cfg), C.byref(ctx)))
         self._ctx = ctx
@@ -317,5 +321,18 @@ class Engine:
         self._chk(self._lib.fwi_last_loop_ms(self._c, C.byref(ms)))
         return ms.value
 
+    def last_host_ms(self):
+        """(submit_ms, graph_build_ms): host wall time spent forming and submitting the last time loop's launches, and
+        the hipGraph capture + instantiation share of it (0 with ``launch_mode="stream"``)."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self._lib.fwi_last_host_ms(self._c, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def synchronize(self):
         self._chk(self._lib.fwi_synchronize(self._c))
+
+    def dirty_padding(self):
+        """Cells of the padded device fields outside the grid's interior that are not exactly zero (must be 0)."""
+        n = C.c_int64(-1)
+        self._chk(self._lib.fwi_check_padding(self._c, C.byref(n)))
+        return int(n.value)

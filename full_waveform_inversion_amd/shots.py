@@ -53,6 +53,29 @@ class Shot:
         engine.adjoint(np.ascontiguousarray(r))
 
 
+def inversion_engine(shape, h, dt, nt_max, **kw):
+    """The :class:`Engine` an INVERSION should run on: ``update_form="increment"`` unless the caller says otherwise.
+
+    In fp32 the standard update form meets north_star's 1e-5 on seismograms and on the gradient of a GIVEN residual,
+    but end to end -- the engine forming its own residual d_syn - d_obs -- the forward error is amplified by |d| / |r|
+    (configs[1] at full size: 6.3e-5; profiles/r03_parity.json).  The increment form carries the same recursion as
+    (u, v = u - u_prev) and meets a flat 1e-5 end to end on every BASELINE config family
+    (tests/test_gpu_parity.py::test_end_to_end_fp32_increment_form_flat_1e5) at +4 B/update in 3-D (157 vs 110 ms per
+    256^3 shot-gradient) and +2.5 % in 2-D.  Forward-only modelling and the headline bench keep the standard form
+    (``Engine``'s default).  fp64 engines need neither; options the increment form does not combine with (the bf16
+    store, an explicit 2-D "stream" kernel) fall back to the standard form.
+    """
+    from .engine import Engine
+    if "update_form" not in kw:
+        fp32 = np.dtype(kw.get("dtype", "float32")) == np.dtype(np.float32)
+        combinable = kw.get("store_dtype", "native") == "native" and not (len(shape) == 2 and kw.get("kernel") == "stream")
+        # 2-D with the convolutional PML: the 4-steps-per-launch kernel that carries the border (step2d_fused_cpml) has
+        # no increment form, and the standard form measures 6.5e-6 end to end there at full size (configs[1] + CPML)
+        cpml2d = len(shape) == 2 and kw.get("abc", "sponge") == "cpml" and kw.get("npml", 0) > 0
+        kw["update_form"] = "increment" if (fp32 and combinable and not cpml2d) else "standard"
+    return Engine(shape, h, dt, nt_max, **kw)
+
+
 def partition_shots(nshots, rank, world):
     """Round-robin: rank r of `world` owns shots r, r + world, ..."""
     if not (0 <= rank < world):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 11
+#define FWI_ABI_VERSION 12
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -53,6 +53,7 @@ enum { FWI_WRT_VELOCITY = 0, FWI_WRT_SLOWNESS2 = 1 };
 enum { FWI_UPDATE_STANDARD = 0, FWI_UPDATE_INCREMENT = 1 };
 enum { FWI_ABC_SPONGE = 0, FWI_ABC_CPML = 1 };
 enum { FWI_STORE_NATIVE = 0, FWI_STORE_BF16 = 1 };
+enum { FWI_LAUNCH_AUTO = 0, FWI_LAUNCH_STREAM = 1, FWI_LAUNCH_GRAPH = 2 };
 
 enum {
     FWI_OK = 0,
@@ -96,7 +97,16 @@ typedef struct fwi_config {
                               FWI_ABC_CPML (convolutional PML: memory variables in the border only) */
     int32_t store_dtype;  /* forward-term store: FWI_STORE_NATIVE (the field type) or FWI_STORE_BF16 (fp32 contexts:
                               half the store and half its traffic; imaging error ~1e-3) */
-    int32_t reserved0;    /* must be 0 */
+    int32_t launch_mode;  /* How the launches of a sweep's time loop reach the GPU.  FWI_LAUNCH_STREAM: one by one on the
+                              context's HIP stream, as they are formed.  FWI_LAUNCH_GRAPH: the whole time loop of a sweep
+                              (every line / step / record launch of fwi_forward or fwi_adjoint) is captured into a hipGraph
+                              and launched once -- same kernels, same arguments, same order, bit-identical results
+                              (SURVEY s.7.2 "or capture the step loop in a hipGraph").  FWI_LAUNCH_AUTO (0, the default):
+                              GRAPH where it was measured to pay -- loops that alternate between DIFFERENT kernels within a
+                              time step (the 3-D convolutional PML: line launch + step kernel, 6 - 13 % less loop time at
+                              256^3) -- and STREAM for loops of one kernel, where the two are equal within noise (2-D fused
+                              launches at every size, the plain 3-D step loop).  DESIGN.md s.4 has the table.
+                              (was reserved0 up to ABI 11) */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the absorbing border, >= 0 (used when npml > 0) */
@@ -204,7 +214,16 @@ int fwi_allreduce_f64_max(fwi_ctx *ctx, double *vals, int32_t n);
 /* Measurement hooks (bench.py): device time of the last time loop, from HIP
  * events on the context's stream, and the synchronising fence. */
 int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out);
+/* Host side of the last time loop: wall time the calling thread spent forming and submitting its launches
+ * (FWI_LAUNCH_GRAPH: capture + instantiation + the one graph launch), and of that the graph's capture + instantiation
+ * alone (0 in stream mode).  Compared with fwi_last_loop_ms it tells whether a loop is bound by the host's launch rate. */
+int fwi_last_host_ms(fwi_ctx *ctx, double *submit_ms_out, double *graph_build_ms_out);
 int fwi_synchronize(fwi_ctx *ctx);
+/* Layout invariant check (tests): the number of cells of the context's padded fields (wavefields, dt^2 c^2, the increment
+ * field, the spare / recomputation pairs) that lie OUTSIDE the grid's interior -- halo planes and rows, the x halo a
+ * row shares with the next, the look-ahead planes, the tail -- and are not exactly zero.  Every kernel relies on those
+ * cells being zero and never writes them; anything but 0 here is a bug. */
+int fwi_check_padding(fwi_ctx *ctx, int64_t *dirty_out);
 /* Name of the stencil kernel the context dispatches to (static string). */
 const char *fwi_kernel_name(const fwi_ctx *ctx);
 /* Device count / name without creating a context (returns FWI_EHIP if none). */

@@ -50,13 +50,13 @@ def test_create_rejects_bad_configs_before_touching_the_gpu():
     ctx = C.c_void_p()
     good = dict(struct_size=C.sizeof(_lib.Config), ndim=3, nz=8, ny=8, nx=8, order=8, nt_max=4, npml=0,
                 device=0, dtype=_lib.F32, kernel=_lib.KERNEL_AUTO, zchunk=0, ckpt_interval=0, image_stride=0,
-                update_form=0, abc=0, store_dtype=0, reserved0=0, pml_alpha_max=0.0, h=10.0,
+                update_form=0, abc=0, store_dtype=0, launch_mode=0, pml_alpha_max=0.0, h=10.0,
                 dt=1e-3,
                 sigma_max=0.0)
     for bad in (dict(ndim=4), dict(order=6), dict(nz=0), dict(nt_max=0), dict(h=0.0), dict(dt=-1.0),
                 dict(dtype=7), dict(struct_size=8), dict(npml=-1), dict(kernel=9), dict(ckpt_interval=-1), dict(image_stride=-1),
                 dict(image_stride=4, ckpt_interval=8), dict(update_form=2), dict(abc=5), dict(store_dtype=3),
-                dict(reserved0=1), dict(store_dtype=1, dtype=_lib.F64), dict(pml_alpha_max=-1.0)):
+                dict(launch_mode=3), dict(store_dtype=1, dtype=_lib.F64), dict(pml_alpha_max=-1.0)):
         cfg = _lib.Config(**{**good, **bad})
         rc = lib.fwi_create(C.byref(cfg), C.byref(ctx))
         assert rc == 1, bad  # FWI_EINVAL

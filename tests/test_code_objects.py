@@ -18,8 +18,8 @@ OBJS = ["fwi_kernels.o", "fwi_stream3d_f32_o8.o", "fwi_stream3d_f32_lo.o", "fwi_
         "fwi_fused2d_pml.o", "fwi_pml.o", "fwi_pair3d.o", "mc_kernels.o"]
 # instantiations per object at the end of round 4 (round 3: fwi_kernels.o alone held 588 stream / tile / point kernels).
 # A change here is deliberate: a new template flag doubles a family, and untested instantiations are where spills hide.
-EXPECTED_MAX = {"fwi_kernels.o": 170, "fwi_stream3d_f32_o8.o": 200, "fwi_stream3d_f32_lo.o": 240, "fwi_stream3d_f64.o": 150,
-                "fwi_fused2d.o": 162, "fwi_fused2d_pml.o": 18, "fwi_pml.o": 130, "fwi_pair3d.o": 3, "mc_kernels.o": 31}
+EXPECTED_MAX = {"fwi_kernels.o": 172, "fwi_stream3d_f32_o8.o": 188, "fwi_stream3d_f32_lo.o": 84, "fwi_stream3d_f64.o": 96,
+                "fwi_fused2d.o": 162, "fwi_fused2d_pml.o": 18, "fwi_pml.o": 126, "fwi_pair3d.o": 3, "mc_kernels.o": 31}
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +45,8 @@ def test_instantiation_counts_do_not_grow_unnoticed(kernels):
     assert set(per) == set(OBJS), per
     over = {o: (n, EXPECTED_MAX[o]) for o, n in per.items() if n > EXPECTED_MAX[o]}
     assert not over, over
-    assert sum(per[o] for o in per if o.startswith("fwi_stream3d") or o == "fwi_kernels.o") < 900
+    # the step / tile / point / helper kernels that made up round 3's fwi_kernels.o (588): 540 now, T-term variants included
+    assert sum(per[o] for o in per if o.startswith("fwi_stream3d") or o == "fwi_kernels.o") < 588
 
 
 def test_stream_kernel_resources_fit_their_launch_bounds(kernels):

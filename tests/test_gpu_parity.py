@@ -599,7 +599,7 @@ def test_bf16_forward_term_store(gpu, shape, npml, stride):
     with pytest.raises(FwiError):
         Engine((40, 40), h, dt, nt, store_dtype="bf16")
     with pytest.raises(FwiError):  # (round 4: the bf16 store exists for the O(8) stencil only)
-        Engine(shape, h, dt, nt, order=4, npml=npml, store_dtype="bf16")
+        Engine(shape, h, dt, nt, order=4, npml=npml, sigma_max=pq.sigma_max, store_dtype="bf16")
 
 
 @pytest.mark.parametrize("shape,npml,stride", [((40, 36, 256), 6, 1), ((33, 29, 50), 5, 1), ((33, 29, 50), 0, 3)])

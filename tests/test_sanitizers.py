@@ -2,7 +2,7 @@
 
 The C oracle is small enough to rebuild with AddressSanitizer + UBSan and run inside the CPU suite; the shim's
 sanitizer build (`make -C full_waveform_inversion_amd/csrc asan`, three minutes of hipcc) runs from
-tests/run_asan.sh, whose last output is kept as profiles/r03_asan.log.  GPU sanitizers need xnack+ code objects,
+tests/run_asan.sh (non-zero exit on any failure or sanitizer report), whose last output is kept as profiles/r04_asan.log.  GPU sanitizers need xnack+ code objects,
 which this pool does not offer: host code only."""
 import os
 import shutil
@@ -49,8 +49,13 @@ def test_c_oracle_under_address_and_ub_sanitizers():
         and "runtime error" not in out, out[-3000:]
 
 
-def test_the_shim_has_a_sanitizer_target_and_a_recorded_run():
+def test_the_sanitizer_script_fails_when_a_run_fails_or_reports():
+    """tests/run_asan.sh used to return tee's status and let sanitizer reports scroll by.  It now exits
+    non-zero on a failed build, a failed pytest run or a report in the output -- checked here on its logic (the full
+    pass is three minutes of hipcc, run by hand / tools; its last log is profiles/r04_asan.log)."""
+    sh = open(os.path.join(ROOT, "tests", "run_asan.sh")).read()
+    assert "pipefail" in sh and "pytest-rc-shim=0" in sh and "pytest-rc-oracle=0" in sh and "exit $rc" in sh
+    assert "ERROR: AddressSanitizer" in sh and "runtime error:" in sh
+    assert "| tail -15" not in sh  # (the pipes that hid pytest's status)
     mk = open(os.path.join(ROOT, "full_waveform_inversion_amd", "csrc", "Makefile")).read()
     assert "-fsanitize=address,undefined" in mk and "asan:" in mk
-    log = open(os.path.join(ROOT, "profiles", "r03_asan.log")).read()
-    assert "passed" in log and "ERROR: AddressSanitizer" not in log and "failed" not in log

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"], help="absorbing border (fwi_config.abc)")
     ap.add_argument("--image-stride", type=int, default=1,
                     help="imaging condition every S-th step (fwi_config.image_stride)")
+    ap.add_argument("--update-form", default="auto", choices=["auto", "increment", "standard"],
+                    help="fp32 update form; auto = shots.inversion_engine's choice (increment: 1e-5 end to end)")
+    ap.add_argument("--launch-mode", default="auto", choices=["auto", "stream", "graph"])
     ap.add_argument("--checkpoint", default="", help="optimiser state file, rewritten after every iteration (rank 0 only)")
     ap.add_argument("--resume", default="", help="continue from such a state file (every rank reads it)")
     a = ap.parse_args()
@@ -47,13 +50,17 @@ def main():
     psize = a.pool or ((3 if a.abc == "cpml" else 2) if w.ndim == 2 else 1)  # (measured: shots.EnginePool)
     from full_waveform_inversion_amd import default_sigma_max
     sigma = default_sigma_max(float(w.c.max()), w.h, w.npml)
-    pool = sh.EnginePool(lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
-                                        sigma_max=sigma, image_stride=a.image_stride, abc=a.abc,
-                                        pml_alpha_max=(3.14159 * w.f0 if a.abc == "cpml" else 0.0)), psize)
+    uf = {} if a.update_form == "auto" else {"update_form": a.update_form}
+    pool = sh.EnginePool(lambda: sh.inversion_engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, device=local,
+                                                     sigma_max=sigma, image_stride=a.image_stride, abc=a.abc,
+                                                     launch_mode=a.launch_mode, **uf,
+                                                     pml_alpha_max=(3.14159 * w.f0 if a.abc == "cpml" else 0.0)), psize)
     e = pool.primary
     ex = sh.NoExchange()
     rdzv = None
-    if world > 1:
+    # FWI_RUN_FORCE_EXCHANGE=1: take the N > 1 path (rendezvous, RCCL communicator, all-reduce per evaluation) with one
+    # rank too -- how a one-GPU box rehearses what the driver's launch line does for N = 2, 4, 8
+    if world > 1 or os.environ.get("FWI_RUN_FORCE_EXCHANGE") == "1":
         # control plane: the package's stdlib rendezvous on MASTER_ADDR / MASTER_PORT (no torch in this process)
         from full_waveform_inversion_amd.rendezvous import Rendezvous
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -89,8 +96,9 @@ def main():
     if rank == 0:
         upd = 2 * evals[0] * len(shots) * w.updates_per_shot  # forward + adjoint sweeps
         print(json.dumps({"config": w.name, "shape": list(w.shape), "nt": w.nt, "shots": len(shots),
-                          "n_gpus": world, "engines_per_gpu": psize, "evaluations": evals[0], "seconds": round(el, 3),
+                          "n_gpus": world, "rccl_ranks": getattr(ex, "rccl_ranks", None), "engines_per_gpu": psize, "evaluations": evals[0], "seconds": round(el, 3),
                           "Gpts_per_s_fwd_plus_adj": round(upd / el / 1e9, 2), "kernel": e.kernel_name,
+                          "update_form": e.update_form, "abc": a.abc, "launch_mode": a.launch_mode,
                           "log": log}))
     pool.close()
     if rdzv is not None:

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--abc", default="sponge", choices=["sponge", "cpml"])
     ap.add_argument("--update-form", default="standard", choices=["standard", "increment"])
     ap.add_argument("--store-dtype", default="native", choices=["native", "bf16"])
+    ap.add_argument("--launch-mode", default="auto", choices=["auto", "stream", "graph"])
     a = ap.parse_args()
     w = workloads.CONFIGS[a.config](a.scale)
     if a.nt:
@@ -32,7 +33,7 @@ def main():
     wav = w.wavelet(np.dtype(a.dtype).type)
     src = w.src_idx[:1]
     e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, kernel=a.kernel, dtype=a.dtype, abc=a.abc,
-               update_form=a.update_form, store_dtype=a.store_dtype, zchunk=a.zchunk,
+               update_form=a.update_form, store_dtype=a.store_dtype, zchunk=a.zchunk, launch_mode=a.launch_mode,
                pml_alpha_max=(3.14159 * w.f0 if a.abc == "cpml" else 0.0))
     e.set_model(w.c.astype(a.dtype))
     npts = int(np.prod(w.shape))
@@ -47,8 +48,8 @@ def main():
         if r:
             for k, v in (("forward", t_f), ("save", t_s), ("adjoint", t_a)):
                 out.setdefault(k, []).append(v)
-    print("%s %s nt=%d order=%d npml=%d kernel=%s dtype=%s abc=%s update_form=%s store_dtype=%s" % (
-        w.name, w.shape, w.nt, w.order, w.npml, e.kernel_name, a.dtype, a.abc, a.update_form, a.store_dtype))
+    print("%s %s nt=%d order=%d npml=%d kernel=%s dtype=%s abc=%s update_form=%s store_dtype=%s launch_mode=%s" % (
+        w.name, w.shape, w.nt, w.order, w.npml, e.kernel_name, a.dtype, a.abc, a.update_form, a.store_dtype, a.launch_mode))
     for k, bpp in (("forward", 16), ("save", 20), ("adjoint", 24)):  # adjoint: paired imaging
         us = 1e3 * float(np.median(out[k])) / w.nt
         g = npts / us / 1e3
