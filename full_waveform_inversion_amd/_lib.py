@@ -70,6 +70,7 @@ SIGNATURES = {
     "fwi_comm_abort": (C.c_int, [_P]),
     "fwi_last_loop_ms": (C.c_int, [_P, C.POINTER(_D)]),
     "fwi_last_host_ms": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D)]),
+    "fwi_set_launch_mode": (C.c_int, [_P, _I32]),
     "fwi_synchronize": (C.c_int, [_P]),
     "fwi_check_padding": (C.c_int, [_P, C.POINTER(_I64)]),
     "fwi_kernel_name": (C.c_char_p, [_P]),

@@ -1080,10 +1080,11 @@ struct Impl {
             struct { void **p; size_t bytes; bool zero; } want[] = {
                 {&ctx->snap, (size_t)nseg * 2 * fb, false},
                 {&ctx->q_store, (size_t)(K + 1) * g.npts * sizeof(T), false},  // K slots + carry
-                {&ctx->fwd[0], fb, false},
-                // (zeroed: in increment form this buffer only ever receives interior points, its halo must read 0;
-                // found by the option fuzz reusing device memory of earlier contexts)
-                {&ctx->fwd[1], fb, true}, {&ctx->fwv, ctx->inc ? fb : 0, false},
+                // (padded fields are zeroed at allocation: in increment form fwd[1] only ever receives interior points and its
+                // halo must read 0 -- found by the option fuzz reusing device memory of earlier contexts; the others are
+                // overwritten whole before use, but fwi_check_padding looks at every padded field of the context)
+                {&ctx->fwd[0], fb, true},
+                {&ctx->fwd[1], fb, true}, {&ctx->fwv, ctx->inc ? fb : 0, true},
                 {&ctx->fwx[0], ctx->fused2d ? fb : 0, true}, {&ctx->fwx[1], ctx->fused2d ? fb : 0, true},
                 {&ctx->pml_psi_fw[0], ctx->pml_bytes[0], false}, {&ctx->pml_zeta_fw[0], ctx->pml_bytes[0], false},
                 {&ctx->pml_psi_fw[1], ctx->pml_bytes[1], false}, {&ctx->pml_zeta_fw[1], ctx->pml_bytes[1], false},
@@ -1651,7 +1652,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     ctx->inc = cfg->update_form == FWI_UPDATE_INCREMENT;
     ctx->cpml = cfg->abc == FWI_ABC_CPML && cfg->npml > 0;
     ctx->qbf16 = cfg->store_dtype == FWI_STORE_BF16;
-    ctx->graph_mode = cfg->launch_mode == FWI_LAUNCH_GRAPH;  // (AUTO is resolved below, once the launch plan is known)
+    ctx->graph_mode = cfg->launch_mode == FWI_LAUNCH_GRAPH;  // (AUTO = stream: the measurement is with the comment below)
     ctx->qes = ctx->qbf16 ? 2 : (cfg->dtype == FWI_F32 ? 4 : 8);
     const bool can_stream = stream_supported(ctx->gd, cfg->dtype == FWI_F32);
     if (cfg->kernel == FWI_KERNEL_STREAM && !can_stream) {
@@ -1711,12 +1712,12 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (ctx->cpml && cfg->ndim == 3) ctx->pml_lines = pml_line_axes(ctx->gd, cfg->npml);
     ctx->xpml = ctx->cpml && ctx->kernel == K_STREAM && ctx->pml_lines == 3 && !getenv("FWI_NO_STREAM_XPML") &&
                 stream_xpml_supported(ctx->gd, ctx->tune, cfg->npml, cfg->dtype == FWI_F32);
-    // launch_mode AUTO: a hipGraph for time loops that alternate between different kernels within a step (measured on
-    // the 3-D CPML, 256^3 / npml 16: forward 91.2 -> 85.6, store 100.7 -> 87.9, adjoint 110.5 -> 106.7 us/step; the graph's
-    // capture + instantiation costs the host what the stream submission did, ~2.3 us per launch); loops of ONE kernel
-    // (2-D fused at 256^2 ... 1024^2 with or without the CPML inside, the plain 3-D step loop) run the same either way
-    // (+-0.7 %, profiles/r04_graph_probe.jsonl) and keep the stream.
-    if (cfg->launch_mode == FWI_LAUNCH_AUTO) ctx->graph_mode = ctx->cpml && !ctx->fused2d;
+    // launch_mode AUTO = stream launches.  hipGraph capture of the time loop was built and measured in round 4 (VERDICT r03
+    // item 3) with the mode switched between sweeps of ONE context: -0.6 % (3-D CPML, two kernels per step) ... +1.4 %
+    // (2-D 256^2) of the loop time, nothing near the 3 % that would justify a second launch path by default; the host is
+    // far ahead of the GPU either way (1.3 ms to submit 500 launches that run 3.1 ms at 256^2).  A first probe that ran the
+    // two modes on two contexts side by side had shown the graph 6 - 13 % ahead on the 3-D CPML: an artefact of that set-up
+    // (the stream-mode context ran 6 % slower than it does alone), which is why the A/B is done on one context now.
     if (getenv("FWI_DEBUG_PML"))
         fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d line-axes=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
                 (int)ctx->fused2d, (int)ctx->xpml, ctx->pml_lines, ctx->tune.ty, ctx->tune.zchunk);
@@ -2137,6 +2138,13 @@ int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_out = ms;
+    return FWI_OK;
+}
+
+int fwi_set_launch_mode(fwi_ctx *ctx, int32_t mode) {
+    if (!ctx) return FWI_EINVAL;
+    if (mode < FWI_LAUNCH_AUTO || mode > FWI_LAUNCH_GRAPH) return ctx->fail(FWI_EINVAL, "fwi_set_launch_mode: unknown mode %d", mode);
+    ctx->graph_mode = mode == FWI_LAUNCH_GRAPH;  // (AUTO = stream, see fwi_create)
     return FWI_OK;
 }
 

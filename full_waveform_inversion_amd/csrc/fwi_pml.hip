@@ -423,7 +423,10 @@ constexpr int PML_LINE_MAXC = 192;  // rows of the coefficient tables (pml_line_
 template <typename T, int R, int D, bool REV, int VL>
 __device__ __forceinline__ void pml_line_body(const PmlArgs<T> &p, const GridDesc &g, int bxi, int boi, int seg, T *ca,
                                               T *cb, int *cin) {
-    constexpr int BS = 4;                          // cells per block = the loads a thread keeps in flight (3 per cell)
+    // cells per block = the loads a thread keeps in flight (3 per cell).  More in flight was measured in round 4 and is
+    // SLOWER (256^3 / npml 16 forward, us/step: this form 87.7; two blocks ahead 89.1; blocks of eight 92.9; 8-byte lanes
+    // with blocks of eight, two ahead 98.0): the extra windows cost registers (up to 360 + AGPR copies), not latency
+    constexpr int BS = 4;
     constexpr int W = (2 * R + BS - 1) / BS * BS;  // warm-up cells ahead of the segment (whole blocks)
     constexpr int NU = BS + 3 * R, NP = BS + 2 * R;
     using V = vecn<T, VL>;
@@ -684,8 +687,7 @@ int pml_line_axes(const GridDesc &g, int npml) {
     return 3;
 }
 
-// 8-byte lanes for fp32, 16-byte for fp64 (256^3 / npml 16 forward, us/step: 4-byte lanes 103-106, 8-byte 99-101,
-// 16-byte 110: measured on the round-3 form).
+// 16-byte lanes for fp64 and (round 4) fp32 O(8), 8-byte for fp32 O(2) / O(4).
 template <typename T, int R, bool REV, int VL>
 static void launch_pml_line_vl(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
     const int nxv = g.cx / VL;
@@ -700,9 +702,13 @@ static void launch_pml_line_vl(const GridDesc &g, const PmlArgs<T> &p, hipStream
 
 template <typename T, int R, bool REV>
 static void launch_pml_line_rev(const GridDesc &g, const PmlArgs<T> &p, hipStream_t s, int axes) {
+    // Lane width: 16 bytes for fp32 O(8) since round 4 (256^3 / npml 16, us/step forward / store / adjoint, two boxes:
+    // 8-byte lanes 87.7 / 94.2 / 107.4 and 87.6 / 96.3 / 108.2, 16-byte 83.7 / 85.9 / 104.8 and 87.3 / 95.8 / 107.1 -- never
+    // slower, up to 9 % faster; the round-3 form with its 5 - 7 operands per cell measured the opposite).
+    // FWI_PML_LINE_VL=2 is the A/B hook.
     if constexpr (std::is_same<T, float>::value && R == 4) {
-        static const bool wide = getenv("FWI_PML_LINE_VL") && atoi(getenv("FWI_PML_LINE_VL")) == 4;  // A/B hook
-        if (wide) return launch_pml_line_vl<T, R, REV, 4>(g, p, s, axes);
+        static const bool narrow = getenv("FWI_PML_LINE_VL") && atoi(getenv("FWI_PML_LINE_VL")) == 2;
+        if (!narrow) return launch_pml_line_vl<T, R, REV, 4>(g, p, s, axes);
     }
     launch_pml_line_vl<T, R, REV, 2>(g, p, s, axes);
 }

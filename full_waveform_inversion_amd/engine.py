@@ -328,6 +328,10 @@ class Engine:
         self._chk(self._lib.fwi_last_host_ms(self._c, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_launch_mode(self, mode):
+        """"auto" / "stream" / "graph" from the next sweep on (an A/B on one context: same buffers, same cache state)."""
+        self._chk(self._lib.fwi_set_launch_mode(self._c, _lib.LAUNCH_MODES[mode]))
+
     def synchronize(self):
         self._chk(self._lib.fwi_synchronize(self._c))
 

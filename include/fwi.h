@@ -101,12 +101,12 @@ typedef struct fwi_config {
                               context's HIP stream, as they are formed.  FWI_LAUNCH_GRAPH: the whole time loop of a sweep
                               (every line / step / record launch of fwi_forward or fwi_adjoint) is captured into a hipGraph
                               and launched once -- same kernels, same arguments, same order, bit-identical results
-                              (SURVEY s.7.2 "or capture the step loop in a hipGraph").  FWI_LAUNCH_AUTO (0, the default):
-                              GRAPH where it was measured to pay -- loops that alternate between DIFFERENT kernels within a
-                              time step (the 3-D convolutional PML: line launch + step kernel, 6 - 13 % less loop time at
-                              256^3) -- and STREAM for loops of one kernel, where the two are equal within noise (2-D fused
-                              launches at every size, the plain 3-D step loop).  DESIGN.md s.4 has the table.
-                              (was reserved0 up to ABI 11) */
+                              (SURVEY s.7.2 "or capture the step loop in a hipGraph").  FWI_LAUNCH_AUTO (0, the default)
+                              resolves to STREAM: measured on one context with the mode switched between sweeps
+                              (profiles/r04_graph_probe.jsonl), the graph changes the loop time by -0.6 ... +1.4 % on every
+                              configuration tried (2-D 256^2 ... 1024^2 with and without the CPML, 3-D 256^3 with one and
+                              with two launches per step) and costs the host the same ~2.3 us per launch to build: a
+                              recorded negative result, DESIGN.md s.4.  (was reserved0 up to ABI 11) */
     double h;            /* grid spacing (m) */
     double dt;           /* time step (s) */
     double sigma_max;    /* peak damping rate (1/s) of the absorbing border, >= 0 (used when npml > 0) */
@@ -218,6 +218,9 @@ int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out);
  * (FWI_LAUNCH_GRAPH: capture + instantiation + the one graph launch), and of that the graph's capture + instantiation
  * alone (0 in stream mode).  Compared with fwi_last_loop_ms it tells whether a loop is bound by the host's launch rate. */
 int fwi_last_host_ms(fwi_ctx *ctx, double *submit_ms_out, double *graph_build_ms_out);
+/* Change fwi_config.launch_mode of a live context (takes effect with the next sweep): the A/B of stream launches against
+ * hipGraph launches on ONE context, the same buffers and the same cache state (tools/graph_probe.py). */
+int fwi_set_launch_mode(fwi_ctx *ctx, int32_t mode);
 int fwi_synchronize(fwi_ctx *ctx);
 /* Layout invariant check (tests): the number of cells of the context's padded fields (wavefields, dt^2 c^2, the increment
  * field, the spare / recomputation pairs) that lie OUTSIDE the grid's interior -- halo planes and rows, the x halo a

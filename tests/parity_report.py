@@ -23,7 +23,17 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def case(name, w, nt=None, dtype="float32", kernel="auto", npml=None, **engine_kw):
+def case(name, w, nt=None, dtype="float32", kernel="auto", npml=None, env=None, **engine_kw):
+    for k, v in (env or {}).items():  # creation-time hooks (FWI_STREAM_TY=8: the 8-row tiles of the HBM-regime grids)
+        os.environ[k] = v
+    try:
+        return _case(name, w, nt, dtype, kernel, npml, env, **engine_kw)
+    finally:
+        for k in (env or {}):
+            os.environ.pop(k, None)
+
+
+def _case(name, w, nt, dtype, kernel, npml, env, **engine_kw):
     if nt:
         w.nt = nt
     if npml is not None:
@@ -51,7 +61,7 @@ def case(name, w, nt=None, dtype="float32", kernel="auto", npml=None, **engine_k
         ge = e.gradient()
         kern = e.kernel_name
     out = {"case": name, "shape": list(w.shape), "nt": w.nt, "order": w.order, "npml": w.npml, "dtype": dtype,
-           "kernel": kern, "engine_options": engine_kw, "seis": rel(dg, d0), "adj_src": rel(ag, a0), "grad_same_r": rel(gg, g0),
+           "kernel": kern, "engine_options": engine_kw, "env": env or {}, "seis": rel(dg, d0), "adj_src": rel(ag, a0), "grad_same_r": rel(gg, g0),
            "grad_e2e": rel(ge, g0), "resid_over_data": float(np.linalg.norm(r) / np.linalg.norm(d0)),
            "oracle_seconds": round(t_cpu, 1)}
     print(json.dumps(out), flush=True)
@@ -85,6 +95,14 @@ def main():
         case("cfg5 128^3 x500 cpml npml 16 increment", workloads.cfg5(0.5), npml=16, abc="cpml", pml_alpha_max=31.0,
              update_form="increment"),
         case("cfg5 128^3 x500 cpml npml 16 fp64", workloads.cfg5(0.5), npml=16, dtype="float64", abc="cpml", pml_alpha_max=31.0),
+        # round 4: the 8-row tiles stream_default_tuning picks for every grid past the Infinity Cache, on oracle-sized grids
+        case("cfg5 128^3 x500, 8-row tiles", workloads.cfg5(0.5), env={"FWI_STREAM_TY": "8"}),
+        case("cfg5 128^3 x500 increment, 8-row tiles", workloads.cfg5(0.5), update_form="increment", env={"FWI_STREAM_TY": "8"}),
+        case("cfg5 128^3 x500 cpml npml 16, 8-row tiles", workloads.cfg5(0.5), npml=16, abc="cpml", pml_alpha_max=31.0,
+             env={"FWI_STREAM_TY": "8"}),
+        case("cfg5 128^3 x500 cpml npml 16 increment, 8-row tiles", workloads.cfg5(0.5), npml=16, abc="cpml",
+             pml_alpha_max=31.0, update_form="increment", env={"FWI_STREAM_TY": "8"}),
+        case("cfg5 128^3 x500 fp64 stream, 8-row tiles", workloads.cfg5(0.5), dtype="float64", env={"FWI_STREAM_TY": "8"}),
     ]
     if len(sys.argv) > 1:
         json.dump(rows, open(sys.argv[1], "w"), indent=1)

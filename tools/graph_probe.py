@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """hipGraph capture of the step loop against plain stream launches (SURVEY s.7.2).
 
-For each workload: the same forward (and store / adjoint) sweeps with fwi_config.launch_mode = stream and = graph,
-interleaved in one process; per mode the device time of the loop (HIP events around it), the host time spent submitting
+For each workload: the same forward (and store / adjoint) sweeps with launch_mode = stream and = graph on ONE context
+(fwi_set_launch_mode between sweeps, alternating which mode goes first); per mode the device time of the loop (HIP events around it), the host time spent submitting
 it, and the share of that spent capturing + instantiating the graph.  One JSON line per workload.
     python tools/graph_probe.py [--rounds 5] > profiles/r04_graph_probe.jsonl
 """
@@ -18,16 +18,18 @@ from full_waveform_inversion_amd import Engine, workloads  # noqa: E402
 
 
 def probe(name, w, rounds, sweeps=("forward",), **kw):
+    """ONE context; the launch mode is switched between sweeps (fwi_set_launch_mode): same buffers, same cache state.
+    Round r runs the modes in the order (stream, graph) when r is even and (graph, stream) when odd, so that neither
+    mode always follows the other; a first round is discarded."""
     wav = w.wavelet(np.float32)
     out = {"workload": name, "shape": list(w.shape), "nt": w.nt, "engine": {k: str(v) for k, v in kw.items()}}
-    eng = {m: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, launch_mode=m, **kw) for m in ("stream", "graph")}
-    res = {m: {s: {"loop_ms": [], "submit_ms": [], "graph_build_ms": []} for s in sweeps} for m in eng}
+    res = {m: {s: {"loop_ms": [], "submit_ms": [], "graph_build_ms": []} for s in sweeps} for m in ("stream", "graph")}
     d = {}
-    try:
-        for m, e in eng.items():
-            e.set_model(w.c.astype(np.float32))
+    with Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, launch_mode="stream", **kw) as e:
+        e.set_model(w.c.astype(np.float32))
         for r in range(rounds + 1):
-            for m, e in eng.items():
+            for m in (("stream", "graph") if r % 2 == 0 else ("graph", "stream")):
+                e.set_launch_mode(m)
                 for s in sweeps:
                     if s == "forward":
                         d[m] = e.forward(None, (w.src_idx[:1], wav), w.rec_idx, save=False)
@@ -40,15 +42,13 @@ def probe(name, w, rounds, sweeps=("forward",), **kw):
                         res[m][s]["loop_ms"].append(e.last_loop_ms())
                         res[m][s]["submit_ms"].append(sub)
                         res[m][s]["graph_build_ms"].append(gb)
-        out["kernel"] = eng["stream"].kernel_name
+        out["kernel"] = e.kernel_name
         out["identical_seismograms"] = bool(np.array_equal(d["stream"], d["graph"]))
-    finally:
-        for e in eng.values():
-            e.close()
     for s in sweeps:
         row = {}
         for m in res:
             row[m] = {k: round(float(np.median(v)), 4) for k, v in res[m][s].items()}
+            row[m]["loop_ms_min_max"] = [round(float(min(res[m][s]["loop_ms"])), 4), round(float(max(res[m][s]["loop_ms"])), 4)]
             row[m]["us_per_step"] = round(1e3 * row[m]["loop_ms"] / w.nt, 4)
         row["graph_over_stream_loop"] = round(row["graph"]["loop_ms"] / row["stream"]["loop_ms"], 4)
         out[s] = row
@@ -57,7 +57,7 @@ def probe(name, w, rounds, sweeps=("forward",), **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     cases = []
