@@ -94,6 +94,26 @@ def test_graph_launch_mode_returns_the_stream_mode_bits(gpu, shape, nt, kw):
     assert np.array_equal(out["graph"][0][0], out["graph"][1][0])
 
 
+def test_graph_mode_in_an_engine_pool_of_threads(gpu):
+    """Capture is thread-local (hipStreamCaptureModeThreadLocal): two contexts driven by two host threads, each capturing
+    its own sweeps on its own stream, give the single-engine gradient -- another thread's synchronising calls (the
+    other context's downloads) must not invalidate a capture in flight."""
+    w = workloads.cfg3(0.125, nshots=4)
+    wav = w.wavelet(np.float32)
+
+    def mk(mode):
+        return lambda: Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, sigma_max=800.0, launch_mode=mode)
+
+    res = {}
+    for mode, size in (("stream", 1), ("graph", 2)):
+        shots = [sh.Shot(w.src_idx[i:i + 1], wav, w.rec_idx) for i in range(4)]
+        with sh.EnginePool(mk(mode), size) as pool:
+            sh.model_data(pool, w.c.astype(np.float32), shots)
+            res[mode] = sh.misfit_and_gradient(pool, w.c_init.astype(np.float32), shots)
+    (J0, g0), (J1, g1) = res["stream"], res["graph"]
+    assert abs(J1 - J0) <= 1e-6 * abs(J0) and rel(g1, g0) < 1e-6  # (two accumulators summed in another order)
+
+
 def test_inversion_engine_defaults_to_the_increment_form(gpu):
     """the mode that meets 1e-5 end to end is the one inversions run -- shots.inversion_engine (and
     configure(), tools/run_config.py) pick update_form="increment" for fp32 unless told otherwise; Engine itself (forward

@@ -59,7 +59,9 @@ def main():
             per_kernel[r["Name"].split("(")[0].replace("void fwi::", "")] = ent
         dom = max(per_kernel.values(), key=lambda e: e["calls"] * e["avg_ns"])
         if leg in PER_STEP and all("traffic_bytes_per_launch" in e for e in per_kernel.values()):
-            steps = max(e["calls"] for k, e in per_kernel.items() if k.startswith("step"))
+            # time steps of the leg = launches of its step kernels (a gradient leg runs several variants: store,
+            # imaging, plain adjoint -- one per time step of either sweep)
+            steps = sum(e["calls"] for k, e in per_kernel.items() if k.startswith("step"))
             dom = {"calls": steps, "avg_ns": sum(e["calls"] * e["avg_ns"] for e in per_kernel.values()) / steps,
                    "traffic_bytes_per_launch": sum(e["calls"] * e["traffic_bytes_per_launch"] for e in per_kernel.values()) / steps,
                    "note": "per TIME STEP: all kernels of the leg (step kernel + line / slab launches) / step-kernel calls"}
