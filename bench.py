@@ -360,10 +360,12 @@ def main():
                      "imaging (24 B/update); the forward-term store (%.1f GiB) streams through HBM",
                      shots=2 if multi else 3)
     if want("gradient_increment"):
-        gradient_leg("gradient_increment", dict(update_form="increment"), 28.0,
+        gradient_leg("gradient_increment", dict(update_form="increment"), 26.0,
                      "256^3 gradient shot, INCREMENT update form (u, v = u - u_prev; the fp32 mode that meets 1e-5 end "
-                     "to end, profiles/r03_parity.json): forward + store 24 B/update, adjoint + imaging 32 B/update; "
-                     "four padded fields = 294 MB do not fit the Infinity Cache; store %.1f GiB", shots=2)
+                     "to end, profiles/r04_parity.json, and what inversions run by default since round 4): forward + store "
+                     "24 B/update, adjoint + PAIRED imaging 28 B/update (round 4: the second pairing takes u_prev = u - v; "
+                     "32 B unpaired before); four padded fields = 294 MB do not fit the Infinity Cache; store %.1f GiB",
+                     shots=2)
     if want("cfg2"):
         def wl():
             w = workloads.cfg2(1.0)

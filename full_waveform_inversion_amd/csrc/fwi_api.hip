@@ -1252,7 +1252,7 @@ struct Impl {
                     pq[hi - n] = mine;
                     pq2[hi - n] = pending;
                     pending = nullptr;
-                } else if (mine && n > lo && ctx->istride == 1 && !ctx->inc) {
+                } else if (mine && n > lo && ctx->istride == 1) {  // (increment form too since round 4: u_prev = u - v)
                     pending = mine;  // first step of a pair: defer (every step images: the next one pairs)
                 } else {
                     pq[hi - n] = mine;  // single (last step of an odd run, or nothing to pair)

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void step_point(StepArgs<T> a, GridDesc g, int
         a.u_prev[p] = un;
         const int64_t ci = ((int64_t)z * g.ny + y) * g.cx + x;
         if (SAVE_Q) a.q_out[ci] = q;
-        if (IMAGE) a.g[ci] += a.q_in2 ? fma(up, a.q_in2[ci], uc * a.q_in[ci]) : uc * a.q_in[ci];
+        // (paired imaging: the second pairing takes u_prev -- in increment form u - v, `up` being v there)
+        if (IMAGE) a.g[ci] += a.q_in2 ? fma(INC ? uc - up : up, a.q_in2[ci], uc * a.q_in[ci]) : uc * a.q_in[ci];
     }
     // injection into the points this workgroup has just written (see the stream kernel)
     if (a.inj_start) {

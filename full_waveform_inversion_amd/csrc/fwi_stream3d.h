@@ -26,7 +26,7 @@ namespace fwi {
 // Infinity Cache traffic.  Blocks are renumbered so each XCD (private 4 MiB
 // L2) owns a contiguous slab of tiles and shares those halo rows on chip.
 // ---------------------------------------------------------------------------
-// IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (two time levels per
+// IMAGE: 0 = off, 1 = g += u_cur * q_in, 2 = additionally g += u_prev * q_in2 (increment form, round 4: u_prev = u_cur - v) (two time levels per
 // read-modify-write of g: the adjoint sweep is HBM-bound, this takes it from 28 to 24 B/update).
 // XP: the convolutional PML of the x border carried in the lanes (1 = forward recursion, 2 = its transpose): the
 // border cells of a row are the first / last npml / 4 lanes of the wave that owns it, psi' of the neighbouring cells
@@ -457,7 +457,8 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
 #pragma unroll
                 for (int j = 0; j < VL; ++j) {
                     gi.v[j] = fma(X[HALO + j], qi.v[j], gi.v[j]);
-                    if (IMAGE == 2) gi.v[j] = fma(up[cp].v[j], qi2.v[j], gi.v[j]);
+                    // (the second pairing takes the field one step further back: u_prev -- in increment form u - v)
+                    if (IMAGE == 2) gi.v[j] = fma(INC ? X[HALO + j] - up[cp].v[j] : up[cp].v[j], qi2.v[j], gi.v[j]);
                 }
             }
             if constexpr (LATE) fetch_pointwise();  // (every use of plane z's pointwise operands lies above)
@@ -502,8 +503,8 @@ static hipError_t launch_stream_family(const StreamLaunch &l, const GridDesc &g,
     if (a.q_out) {
         if constexpr (DIR >= 0) FWI_STREAM_GO(true, 0);
         else return hipErrorInvalidValue;
-    } else if (a.q_in && a.q_in2 && !INC) {  // (increment form: the adjoint sweep images one pairing per step)
-        if constexpr (DIR <= 0 && !INC) FWI_STREAM_GO(false, 2);
+    } else if (a.q_in && a.q_in2) {
+        if constexpr (DIR <= 0) FWI_STREAM_GO(false, 2);
         else return hipErrorInvalidValue;
     } else if (a.q_in) {
         if constexpr (DIR <= 0) FWI_STREAM_GO(false, 1);

@@ -18,7 +18,7 @@ OBJS = ["fwi_kernels.o", "fwi_stream3d_f32_o8.o", "fwi_stream3d_f32_lo.o", "fwi_
         "fwi_fused2d_pml.o", "fwi_pml.o", "fwi_pair3d.o", "mc_kernels.o"]
 # instantiations per object at the end of round 4 (round 3: fwi_kernels.o alone held 588 stream / tile / point kernels).
 # A change here is deliberate: a new template flag doubles a family, and untested instantiations are where spills hide.
-EXPECTED_MAX = {"fwi_kernels.o": 172, "fwi_stream3d_f32_o8.o": 188, "fwi_stream3d_f32_lo.o": 84, "fwi_stream3d_f64.o": 96,
+EXPECTED_MAX = {"fwi_kernels.o": 172, "fwi_stream3d_f32_o8.o": 208, "fwi_stream3d_f32_lo.o": 96, "fwi_stream3d_f64.o": 96,
                 "fwi_fused2d.o": 162, "fwi_fused2d_pml.o": 18, "fwi_pml.o": 128, "fwi_pair3d.o": 3, "mc_kernels.o": 31}
 
 

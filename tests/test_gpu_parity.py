@@ -1054,6 +1054,11 @@ def fuzz_option_combinations(seed, ncases, setenv, maxdim=37):
         pair = nd == 3 and rng.random() < 0.5
         stride = int(rng.choice([1, 1, 3])) if ck == 0 else 1
         setenv("FWI_STREAM_PAIR", "1" if pair else "0")
+        # round 4: the tile shape of the 3-D stream kernel (8 rows = what grids past the Infinity Cache run) and the way
+        # the time loop is submitted (one hipGraph per sweep) are part of the option space as well
+        ty8 = bool(rng.random() < 0.5)
+        setenv("FWI_STREAM_TY", "8" if ty8 else "4")
+        launch = str(rng.choice(["stream", "graph"]))
         kw = dict(abc=abc, pml_alpha_max=alpha, image_stride=stride)
         if bf16:
             p = fo.Propagator(c, h, dt, order, npml, store_dtype="bf16", **kw)
@@ -1064,13 +1069,13 @@ def fuzz_option_combinations(seed, ncases, setenv, maxdim=37):
         g = p.gradient()
         poison_device_memory(64)
         with Engine(shape, h, dt, nt, order=order, npml=npml, sigma_max=p.sigma_max, ckpt_interval=ck,
-                    update_form=form, store_dtype="bf16" if bf16 else "native", **kw) as e:
+                    update_form=form, store_dtype="bf16" if bf16 else "native", launch_mode=launch, **kw) as e:
             d0 = e.forward(c, (src, w), rec, save=False)   # (3-D, no border: the two-step kernel when enabled)
             dg = e.forward(None, (src, w), rec, save=True)
             ag = e.adjoint(r)
             gg = e.gradient()
             kern = e.kernel_name
-        tag = (seed, case, shape, order, npml, nt, abc, alpha, form, bf16, ck, pair, stride, kern)
+        tag = (seed, case, shape, order, npml, nt, abc, alpha, form, bf16, ck, pair, stride, kern, ty8, launch)
         gtol = 5e-5
         if bf16:
             # fp32 and fp64 values of C L u that straddle a bf16 rounding boundary round apart by a whole bf16 ulp (the

@@ -17,11 +17,11 @@ SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r0
 DST = os.path.join(ROOT, "profiles")
 # algorithmic bytes per launch (SURVEY s.8d): 16 B/update forward; gradient shot 22 B averaged over the forward+store
 # (20 B) and adjoint + paired-imaging (24 B) launches; the 2-D fused kernel advances 4 time steps per launch
-# increment form: forward + store 24 B, adjoint + imaging 32 B; bf16 store: 18 B / 20 B; fp64: 32 B; the CPML legs add
+# increment form: forward + store 24 B, adjoint + paired imaging 28 B (round 4; 32 B unpaired before); bf16 store: 18 B / 20 B; fp64: 32 B; the CPML legs add
 # the memory variables (psi, zeta read + written: 16 B per border cell and axis) -- per launch of 4 steps in 2-D, per
 # time step (step kernel + slab launches together) in 3-D
 N3 = 256 ** 3
-LEGS = {"headline": 16.0 * N3, "hbm": 16.0 * 512 ** 3, "gradient": 22.0 * N3, "gradient_increment": 28.0 * N3,
+LEGS = {"headline": 16.0 * N3, "hbm": 16.0 * 512 ** 3, "gradient": 22.0 * N3, "gradient_increment": 26.0 * N3,
         "cfg2": 4 * 16.0 * 1024 ** 2, "cfg2_cpml": 4 * 16.0 * 1024 ** 2 + 16.0 * 2 * 2 * 40 * 1024,
         "cpml3d": 16.0 * N3 + 16.0 * 3 * 2 * 16 * 256 ** 2, "fp64": 32.0 * N3, "point": 16.0 * N3, "bf16": 19.0 * N3,
         # the CPML gradient sweeps (store 20 B + adjoint with paired imaging 24 B, averaged) and the HBM-regime CPML run
