@@ -212,13 +212,15 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
     if constexpr (TP) {
         const int nsy = pml_shell_rows(g.ny, a.npml, R);
         yin = act && pml_in_shell(y, g.ny, a.npml, R);
-        tyoff = yin ? (unsigned)(pml_shell_index(y, g.ny, a.npml, R) * g.cx + x0) : (act ? (unsigned)x0 : 0u);
+        tyoff = yin ? (unsigned)(pml_shell_index(y, g.ny, a.npml, R) * g.cx + x0) : 0u;  // (off the shell: ONE address)
         typl = yin ? (int64_t)nsy * g.cx : 0;
     }
-    auto tz_at = [&](int p) {  // plane p of the z term (clamped; planes off the shell: shell plane 0, discarded)
+    auto tz_at = [&](int p) {  // plane p of the z term (clamped); planes off the shell: every lane re-reads the array's
+                               // first vector (one cache line per wave instead of a plane-sized footprint) and discards it
         const int pc = min(p, g.nz - 1);
-        const int sp = pml_in_shell(pc, g.nz, a.npml, R) ? pml_shell_index(pc, g.nz, a.npml, R) : 0;
-        return ldv<T>(a.pml_tz + (int64_t)sp * cplane + tco);
+        const bool in = pml_in_shell(pc, g.nz, a.npml, R);
+        const int sp = in ? pml_shell_index(pc, g.nz, a.npml, R) : 0;
+        return ldv<T>(a.pml_tz + (int64_t)sp * cplane + (in ? tco : 0u));
     };
     // (the array holds nz + 1 planes: the prefetch of the plane behind the last one needs no clamp)
     auto ty_at = [&](int p) { return ldv<T>(a.pml_ty + (int64_t)p * typl + tyoff); };
@@ -337,13 +339,23 @@ __global__ __launch_bounds__(64 * TY) void step3d_stream(StepArgs<T> a, GridDesc
             V xterm, xn0, xn1;
             if constexpr (XP != 0) {
                 T W[2 * HALO + VL];  // [left lane's cells][own][right lane's] of a quantity, zero beyond the wave
+                // neighbours by DPP (wave_shr:1 / wave_shl:1, GFX9 family: a cross-lane move in the VALU, zero where the
+                // wave ends) instead of __shfl_up / __shfl_down, which hipcc lowers to ds_bpermute -- an LDS-crossbar round
+                // trip per value, 8 - 24 of them in a dependent chain per plane; at one or two waves per SIMD that chain is
+                // what the in-between grid sizes pay for the x border (384^3: step kernel 296 -> see DESIGN.md s.4 CPML)
                 auto spread = [&](const V &v) __attribute__((always_inline)) {
 #pragma unroll
                     for (int j = 0; j < VL; ++j) {
-                        const T l = __shfl_up(v.v[j], 1, 64), r = __shfl_down(v.v[j], 1, 64);
-                        W[j] = lane == 0 ? T(0) : l;
+                        if constexpr (std::is_same<T, float>::value) {
+                            const int b = __builtin_bit_cast(int, v.v[j]);
+                            W[j] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x138, 0xf, 0xf, true));
+                            W[HALO + VL + j] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, b, 0x130, 0xf, 0xf, true));
+                        } else {
+                            const T l = __shfl_up(v.v[j], 1, 64), r = __shfl_down(v.v[j], 1, 64);
+                            W[j] = lane == 0 ? T(0) : l;
+                            W[HALO + VL + j] = lane == 63 ? T(0) : r;
+                        }
                         W[HALO + j] = v.v[j];
-                        W[HALO + VL + j] = lane == 63 ? T(0) : r;
                     }
                 };
                 const V m0 = xps[cp], m1 = xzt[cp];
