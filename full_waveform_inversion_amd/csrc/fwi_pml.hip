@@ -516,10 +516,14 @@ __device__ __forceinline__ void pml_line_body(const PmlArgs<T> &p, const GridDes
     };
     // rows whose inputs a block at i0 needs (REV: zt sits 2r ahead like the field, pt r ahead; forward: psi r ahead,
     // zeta at the block's own rows)
+    // (field rows past ie - 1 + r meet zero coefficients only -- psi', alpha vanish off the border and E reaches r rows --
+    // so the window's far end, and the look-ahead of the last block, re-read that row instead of fetching planes nobody
+    // uses: 8 of 32 planes per segment in O(8))
+    const int jtop = ie - 1 + R;
     auto issue = [&](int i0, In &in) {
 #pragma unroll
         for (int t = 0; t < BS; ++t) {
-            in.un[t] = ldf(p.u_cur, i0 + 2 * R + t);
+            in.un[t] = ldf(p.u_cur, min(i0 + 2 * R + t, jtop));
             in.o0[t] = ldm(m0, REV ? i0 + 2 * R + t : i0 + R + t);
             in.o1[t] = ldm(m1, REV ? i0 + R + t : i0 + t);
         }
