@@ -1,3 +1,8 @@
+# Round-3 tree against the round-4 tree on ONE box in ONE gpurun call (profiles/r04_ab_r03_vs_r04.json).
+# Set-up (in the container, before the call; variant_build/ is git-ignored but travels to the GPU box):
+#   git worktree add -f variant_build/r03tree cc82a3c && make -C variant_build/r03tree/full_waveform_inversion_amd/csrc -j8 \
+#     && make -C variant_build/r03tree/oracle      (and `git worktree remove --force variant_build/r03tree` afterwards)
+# Run on the GPU box: bash tools/ab_r03_vs_r04.sh
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04ab
