@@ -97,6 +97,23 @@ def test_the_gradient_leg_times_the_real_exchange_pattern_and_checks_the_sum(gpu
     assert leg["update_form"] == "standard" and leg["Gpts_per_s_both_sweeps"] > 20
 
 
+def test_a_failed_all_reduce_check_is_fatal_not_a_field_in_the_line(gpu):
+    """a wrong or skipped RCCL sum must not exit 0 with a headline figure.  Rehearsed with one rank: the
+    check is told to expect the sum of TWO ranks (FWI_BENCH_CHECK_EXPECT_RANKS=2), g.g after / before is 1 instead of 4,
+    every rank learns the outcome over RCCL and the process ends non-zero without a JSON line."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, FWI_BENCH_FORCE_EXCHANGE="1", FWI_BENCH_CHECK_EXPECT_RANKS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--leg", "gradient", "--leg-nt", "100"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600, env=env)
+    assert p.returncode != 0
+    assert b"all-reduce check FAILED" in p.stderr and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
 def test_the_cpml_legs_report_the_kernels_that_carry_the_border(gpu):
     d = _run("--leg", "cfg2_cpml", "--leg-nt", "200")
     leg = d["legs"]["cfg2_cpml"]
