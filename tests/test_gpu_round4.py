@@ -13,6 +13,8 @@ from oracle import fwi_oracle as fo
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _mms  # noqa: E402  (the manufactured problems: exact solutions on a heterogeneous medium)
 
 
 def rel(a, b):
@@ -154,3 +156,78 @@ def test_run_config_under_the_drivers_launch_line_with_one_rank(gpu, tmp_path):
     from full_waveform_inversion_amd.lbfgs import load_state
     st = load_state(ck)
     assert st["it"] == 2 and st["history"] == 5 and st["x"].shape == tuple(r["shape"])
+
+
+class _GpuProp:
+    """The oracle classes' constructor / forward signature over the GPU engine (tests/_mms.error drives either)."""
+
+    def __init__(self, c, h, dt, order, npml, sigma_max=None, dtype="float32", **kw):
+        self.c, self.args, self.kw, self.dtype = c, (h, dt, order, npml, sigma_max), kw, dtype
+
+    def forward(self, src, wav, rec, save=False):
+        h, dt, order, npml, sigma_max = self.args
+        with Engine(self.c.shape, h, dt, wav.shape[0], order=order, npml=npml, sigma_max=sigma_max, dtype=self.dtype,
+                    **self.kw) as e:
+            d = e.forward(self.c, (src, wav), rec, save=save)
+            self.kernel = e.kernel_name
+        return d
+
+
+@pytest.mark.parametrize("dtype,stream_ty", [("float32", None), ("float32", "8"), ("float64", None)])
+def test_gpu_kernels_against_the_exact_solution_on_a_heterogeneous_medium_3d(gpu, monkeypatch, dtype, stream_ty):
+    """No oracle in between: the 3-D stream kernel (4- and 8-row tiles, fp32 and fp64) against a MANUFACTURED exact solution
+    on a smoothly varying c(x) -- 68 921 sources (one per node of the 41^3 grid) carry the closed-form source term -- with
+    the sponge and with the convolutional PML (x border in the lanes, z / y terms handed over by the line launch).  The
+    error against the exact solution is the scheme's discretisation error: it falls 4x from 21^3 to 41^3 (dt ~ h with the
+    sponge, dt ~ h^2 with the CPML) exactly as the oracle's does (tests/test_oracle.py), and the two errors agree to the
+    engine's arithmetic: the GPU kernels and the oracle converge to the SAME continuous solution at the same rate."""
+    from functools import partial
+    from oracle.c_oracle import CPropagator
+    if stream_ty:
+        monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
+    gp = partial(_GpuProp, dtype=dtype)
+    dt0 = 0.5 * fo.cfl_dt(2740.0, _mms.X / 20, 3, 8)
+    eg, eo = [], []
+    for n in (21, 41):
+        case = _mms.sponge_case(n, dt0 * 20.0 / (n - 1), 3, 6)
+        eg.append(_mms.error(case, gp))
+        eo.append(_mms.error(case, CPropagator))
+    assert 3.5 < eg[0] / eg[1] < 4.5 and eg[1] < 1e-4, eg          # 3.3e-4 -> 8.2e-5
+    # the two errors agree to the engine's arithmetic: 1e-9 of the error in fp64; in fp32 the solution itself carries ~3e-7
+    # of round-off, i.e. up to 1 % of a 3e-5 discretisation error
+    close = (lambda a, b: abs(a - b) <= 1e-9 * b) if dtype == "float64" else (lambda a, b: abs(a - b) <= 5e-3 * b + 5e-7)
+    assert all(close(a, b) for a, b in zip(eg, eo)), (eg, eo)
+    eg, eo = [], []
+    for n, dt in ((21, 3.2e-3), (41, 8e-4)):
+        case = _mms.cpml_case(n, dt, 60.0, 3)
+        eg.append(_mms.error(case, gp))
+        eo.append(_mms.error(case, CPropagator))
+    assert 3.2 < eg[0] / eg[1] < 5.0 and eg[1] < 2e-3, eg          # 5.5e-3 -> 1.4e-3
+    assert all(close(a, b) for a, b in zip(eg, eo)), (eg, eo)
+
+
+def test_gpu_fused_2d_kernels_against_the_exact_solution(gpu):
+    """The same in 2-D through step2d_fused (4 time steps per launch; one source per node injected inside the sub-steps):
+    with the sponge 41^2 -> 81^2, error 4x smaller and equal to the oracle's; with the CPML INSIDE the fused launch (257^2:
+    five tiles per axis with the overlap seam, npml 32) the error against the exact solution equals the oracle's."""
+    from oracle.c_oracle import CPropagator
+
+    def gpu_error(case):
+        g = _GpuProp(case["c"], case["h"], case["dt"], 8, case["npml"], sigma_max=case["sigma_max"], **case["kw"])
+        d = np.asarray(g.forward(case["src"], case["wav"], case["rec"]), np.float64)
+        return float(np.linalg.norm(d - case["exact"]) / np.linalg.norm(case["exact"])), g.kernel
+
+    dt0 = 0.5 * fo.cfl_dt(2640.0, _mms.X / 40, 2, 8)
+    eg, eo = [], []
+    for n in (41, 81):
+        case = _mms.sponge_case(n, dt0 * 40.0 / (n - 1), 2, 6)
+        e, kern = gpu_error(case)
+        assert kern == "step2d_fused"
+        eg.append(e)
+        eo.append(_mms.error(case, CPropagator))
+    assert 3.6 < eg[0] / eg[1] < 4.4, eg
+    assert all(abs(a - b) <= 5e-3 * b + 5e-7 for a, b in zip(eg, eo)), (eg, eo)  # (fp32 round-off ~3e-7 of the solution)
+    case = _mms.cpml_case(257, 2e-4, 60.0, 2, power=4, npml=32)   # (5 tiles per axis with the overlap seam: the fused CPML launch)
+    e, kern = gpu_error(case)
+    eo1 = _mms.error(case, CPropagator)
+    assert kern == "step2d_fused" and e < 2e-4 and abs(e - eo1) <= 5e-3 * eo1 + 5e-7, (kern, e, eo1)

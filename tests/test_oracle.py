@@ -9,8 +9,12 @@ so that later edits cannot silently change the definition.
 """
 import os
 
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import fwi_oracle as fo
 from oracle.c_oracle import CPropagator
@@ -274,54 +278,16 @@ def test_observed_convergence_orders():
 # evaluated in closed form and injected at every node, and the oracle's field must converge to u at the scheme's
 # orders -- an independent solution for variable C, for the sponge and (further down) for the CPML's coefficients.
 # ---------------------------------------------------------------------------
-_MMS_X, _MMS_TG, _MMS_TEND = 400.0, 0.2, 0.15   # box edge (m), period of g, final time (s)
+import _mms  # noqa: E402  (tests/_mms.py: the manufactured problems, 2-D and 3-D; shared with the GPU suite)
+
+_MMS_X = _mms.X
 
 
-def _sink(t, k):
-    """sin^k(t) and its first two derivatives with respect to t."""
-    s, co = np.sin(t), np.cos(t)
-    return s ** k, k * s ** (k - 1) * co, k * (k - 1) * s ** (k - 2) * co ** 2 - k * s ** k
-
-
-def _mms_medium(n):
-    x = np.arange(n) * (_MMS_X / (n - 1))
-    Z, Xg = np.meshgrid(x, x, indexing="ij")
-    c = 2000.0 * (1 + 0.2 * np.sin(2 * np.pi * Xg / _MMS_X) * np.cos(2 * np.pi * Z / _MMS_X) + 0.1 * Z / _MMS_X)
-    return x, c
-
-
-def _mms_points(n):
-    src = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2)
-    st = max(1, (n - 1) // 20)   # receivers: the nodes of the coarsest level, at every level
-    rec = np.stack(np.meshgrid(np.arange(0, n, st), np.arange(0, n, st), indexing="ij"), -1).reshape(-1, 2)
-    return src, rec, st
-
-
-def _mms_sponge_error(n, order, dt, power=8, sigma_max=150.0, prop=CPropagator):
-    """Relative L2 error over all recorded samples of the 2-D sponge scheme against the manufactured solution
-    u = sin^4(pi t / Tg) sin^p(pi z / X) sin^p(pi x / X) of  u_tt + sigma(x) u_t = c(x)^2 (lap u + S)  -- the
-    continuous equation the damped leapfrog step A (2u - B u_prev + q) discretises (sigma = 2 d / dt); sigma is the
-    quadratic ramp over a quarter of the box, where u is 1e-2 .. 1e-1 of its peak."""
-    X, Tg = _MMS_X, _MMS_TG
-    h = X / (n - 1)
-    npml = (n - 1) // 4
-    nt = int(round(_MMS_TEND / dt))
-    dt = _MMS_TEND / nt
-    x, c = _mms_medium(n)
-    prof = fo.damping_profiles((n, n), npml, sigma_max, dt)
-    sig = (prof[0][:, None] + prof[1][None, :]) * 2.0 / dt
-    f0, _, f2 = _sink(np.pi * x / X, power)
-    f2 = f2 * (np.pi / X) ** 2
-    phi = f0[:, None] * f0[None, :]
-    lap = f2[:, None] * f0[None, :] + f0[:, None] * f2[None, :]
-    t = np.arange(nt) * dt
-    g, g1, g2 = _sink(np.pi * t / Tg, 4)
-    g1, g2 = g1 * np.pi / Tg, g2 * (np.pi / Tg) ** 2
-    S = (g2[:, None] * phi.ravel() + g1[:, None] * (sig * phi).ravel()) / c.ravel() ** 2 - g[:, None] * lap.ravel()
-    src, rec, st = _mms_points(n)
-    d = prop(c, h, dt, order, npml, sigma_max=sigma_max).forward(src, S * h ** 2, rec, save=False)
-    ex = _sink(np.pi * (t + dt) / Tg, 4)[0][:, None] * phi[::st, ::st].ravel()[None]
-    return float(np.linalg.norm(d - ex) / np.linalg.norm(ex))
+def _mms_sponge_error(n, order, dt, power=8, sigma_max=150.0, prop=CPropagator, ndim=2):
+    """Relative L2 error over all recorded samples of the sponge scheme against the manufactured solution
+    u = sin^4(pi t / Tg) prod_d sin^p(pi x_d / X) of  u_tt + sigma(x) u_t = c(x)^2 (lap u + S); sigma is the quadratic
+    ramp over a quarter of the box, where u is 1e-2 .. 1e-1 of its peak."""
+    return _mms.error(_mms.sponge_case(n, dt, ndim, power, sigma_max), prop, order)
 
 
 def test_manufactured_solution_heterogeneous_medium_with_sponge_second_order_in_time():
@@ -347,57 +313,11 @@ def test_manufactured_solution_space_order_eight():
     assert e[0] / e[1] > 128.0 and e[1] < 1e-6, e
 
 
-def _mms_cpml_error(n, dt, alpha_max, order=8, sigma_max=150.0, power=8, prop=CPropagator):
-    """The same manufactured u on the same medium with the CONVOLUTIONAL PML.  The recursions psi <- b psi + a D u,
-    zeta <- b zeta + a (E u + D psi) with b = exp(-(sigma + alpha) dt), a = sigma / (sigma + alpha) (b - 1) are the
-    exponential integrators of
-        psi_t = -lam psi - sigma u_x,   zeta_t = -lam zeta - sigma (u_xx + psi_x),   lam = sigma + alpha
-    (forcing held at its newest value over a step: first order in dt), and the field obeys
-        u_tt = c^2 (lap u + sum_d (d_d psi_d + zeta_d) + S).
-    For u = g(t) phi(x) the memory variables are convolutions of g with exp(-lam t): psi = -sigma phi_x G,
-    zeta = -sigma (phi_xx G - (sigma phi_x)_x H - sigma phi_x lam_x K) with G' = -lam G + g, H' = -lam H + G,
-    Gl = dG/dlam (Gl' = -lam Gl - G), K' = -lam K + Gl -- four scalar linear ODEs per distinct lam (one per border
-    node of an axis), integrated here to 1e-12 by an 8th-order Runge-Kutta: independent of the finite-difference
-    scheme.  S then follows in closed form."""
-    from scipy.integrate import solve_ivp
-    X, Tg = _MMS_X, _MMS_TG
-    h = X / (n - 1)
-    npml = (n - 1) // 4
-    L = npml * h
-    nt = int(round(_MMS_TEND / dt))
-    dt = _MMS_TEND / nt
-    x, c = _mms_medium(n)
-    xi = np.maximum(0.0, np.maximum(L - x, x - (X - L))) / L           # dist / npml as a function of x
-    sgn = np.where(x < L, -1.0, np.where(x > X - L, 1.0, 0.0))          # L d(xi)/dx
-    sig, dsig = sigma_max * xi ** 2, 2.0 * sigma_max * xi * sgn / L
-    lam, dlam = sig + alpha_max * (1.0 - xi), dsig - alpha_max * sgn / L
-    t = np.arange(nt) * dt
-    ker, cache = np.zeros((4, nt, n)), {}
-    for i in np.nonzero(xi > 0)[0]:
-        key = round(float(lam[i]), 9)
-        if key not in cache:
-            li = float(lam[i])
-            cache[key] = solve_ivp(lambda tt, y: [-li * y[0] + np.sin(np.pi * tt / Tg) ** 4, -li * y[1] + y[0],
-                                                  -li * y[2] - y[0], -li * y[3] + y[2]],
-                                   (0.0, _MMS_TEND), [0.0] * 4, method="DOP853", rtol=1e-12, atol=1e-16, t_eval=t).y
-        ker[:, :, i] = cache[key]
-    G, H, Gl, K = ker
-    f0, f1, f2 = _sink(np.pi * x / X, power)
-    f1, f2 = f1 * np.pi / X, f2 * (np.pi / X) ** 2
-    sf1, dsf1 = sig * f1, dsig * f1 + sig * f2
-    # one axis' d psi / dx + zeta as a function of (t, its coordinate), for a unit transverse factor
-    term = (-(dsf1[None] * G) - (sf1 * dlam)[None] * Gl) - sig[None] * (f2[None] * G - dsf1[None] * H - (sf1 * dlam)[None] * K)
-    g, _, g2 = _sink(np.pi * t / Tg, 4)
-    g2 = g2 * (np.pi / Tg) ** 2
-    phi = f0[:, None] * f0[None, :]
-    lap = f2[:, None] * f0[None, :] + f0[:, None] * f2[None, :]
-    S = (g2[:, None, None] * phi[None] / c[None] ** 2 - g[:, None, None] * lap[None]
-         - term[:, :, None] * f0[None, None, :] - f0[None, :, None] * term[:, None, :])
-    src, rec, st = _mms_points(n)
-    p = prop(c, h, dt, order, npml, sigma_max=sigma_max, abc="cpml", pml_alpha_max=alpha_max)
-    d = p.forward(src, S.reshape(nt, -1) * h ** 2, rec, save=False)
-    ex = _sink(np.pi * (t + dt) / Tg, 4)[0][:, None] * phi[::st, ::st].ravel()[None]
-    return float(np.linalg.norm(d - ex) / np.linalg.norm(ex))
+def _mms_cpml_error(n, dt, alpha_max, order=8, sigma_max=150.0, power=8, prop=CPropagator, ndim=2):
+    """The same manufactured u on the same medium with the CONVOLUTIONAL PML; the memory variables of the continuous PML
+    system are obtained semi-analytically (tests/_mms.py: four linear ODEs per border node, 8th-order Runge-Kutta to
+    1e-12), independently of the finite-difference scheme."""
+    return _mms.error(_mms.cpml_case(n, dt, alpha_max, ndim, power, sigma_max), prop, order)
 
 
 @pytest.mark.parametrize("alpha_max,last", [(60.0, 1e-4), (0.0, 3e-4)])
@@ -411,6 +331,15 @@ def test_manufactured_solution_heterogeneous_medium_with_cpml(alpha_max, last):
     assert e[2] < last, e
     e_np = _mms_cpml_error(41, 1.6e-3, alpha_max, prop=fo.Propagator)
     assert abs(e_np - e[0]) < 1e-9 * e[0]
+
+
+def test_manufactured_solution_in_three_dimensions():
+    """The same rung in 3-D (what the stream kernel computes): sponge, dt ~ h, 21^3 -> 41^3: 4x; CPML, dt ~ h^2: 4x."""
+    dt0 = 0.5 * fo.cfl_dt(2740.0, _MMS_X / 20, 3, 8)
+    e = [_mms_sponge_error(n, 8, dt0 * 20.0 / (n - 1), power=6, ndim=3) for n in (21, 41)]
+    assert 3.5 < e[0] / e[1] < 4.5 and e[1] < 3e-4, e
+    e = [_mms_cpml_error(n, dt, 60.0, ndim=3) for n, dt in ((21, 3.2e-3), (41, 8e-4))]
+    assert 3.2 < e[0] / e[1] < 5.0 and e[1] < 3e-3, e
 
 
 # ---------------------------------------------------------------------------
