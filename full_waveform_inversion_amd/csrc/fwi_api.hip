@@ -1669,7 +1669,15 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
         ctx->kernel = K_POINT;
     }
     if (ctx->kernel == K_STREAM) {
-        ctx->tune = stream_default_tuning(ctx->gd, cfg->dtype == FWI_F32);
+        // what a time step touches beside the three fields: the increment field; the CPML's memory variables (psi, zeta
+        // over 2 npml planes per axis) and the handed-over border terms (two shells of npml + r)
+        double extra = ctx->inc ? (double)ctx->gd.ptot * ctx->esize : 0.0;
+        if (ctx->cpml && cfg->ndim == 3) {
+            const double face[3] = {(double)ctx->gd.ny * ctx->gd.cx, (double)ctx->gd.nz * ctx->gd.cx, (double)ctx->gd.nz * ctx->gd.ny};
+            for (int d = 0; d < 3; ++d) extra += 2.0 * std::min(2 * cfg->npml, d == 0 ? cfg->nz : d == 1 ? cfg->ny : cfg->nx) * face[d] * ctx->esize;
+            for (int d = 0; d < 2; ++d) extra += 2.0 * (cfg->npml + ctx->gd.r) * face[d] * ctx->esize;
+        }
+        ctx->tune = stream_default_tuning(ctx->gd, cfg->dtype == FWI_F32, extra);
         if (cfg->zchunk > 0) ctx->tune.zchunk = cfg->zchunk;
         if (const char *pf = getenv("FWI_STREAM_PF")) {  // tuning hook: prefetch depth in planes
             const int v = atoi(pf);

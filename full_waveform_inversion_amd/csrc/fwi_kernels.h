@@ -114,7 +114,10 @@ int point_num_tiles(const GridDesc &g);
 
 // True when the stream kernel supports this grid / dtype.
 bool stream_supported(const GridDesc &g, bool is_f32);
-StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32);
+// `extra_bytes`: what a time step touches beside the three padded fields (the increment form's fourth field, the CPML's
+// memory variables and handed-over terms): it decides whether the step is Infinity-Cache resident, i.e. which regime the
+// launch shape is chosen for.
+StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32, double extra_bytes = 0.0);
 
 template <typename T>
 hipError_t launch_step(int kernel, const GridDesc &g, const StepArgs<T> &a, const StreamTuning &t,

@@ -287,7 +287,7 @@ bool stream_xpml_supported(const GridDesc &g, const StreamTuning &t, int npml, b
     return tw >= npml + g.r && g.nx - (nxt - 1) * tw >= npml + g.r;
 }
 
-StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
+StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32, double extra_bytes) {
     const int full_x = is_f32 ? 256 : 128, vl = is_f32 ? 4 : 2;
     // 3-D: split nx into equal x tiles (multiples of the lane vector) rather than full ones plus a remainder
     const int nxt0 = (g.nx + full_x - 1) / full_x;
@@ -327,8 +327,18 @@ StreamTuning stream_default_tuning(const GridDesc &g, bool is_f32) {
     }
     constexpr double CUS = 256.0, PROLOGUE = 10.0;
     // (200 MiB: 256^3 = 192 MiB is resident, 272^3 = 230 MiB measurably is not -- it runs 12 % faster tuned as HBM)
-    const bool cache_resident = 3.0 * (double)g.npts * (is_f32 ? 4 : 8) <= 200.0 * 1024 * 1024;
-    const double WSAT = cache_resident ? 256.0 : 200.0, TY4_PENALTY = cache_resident ? 1.0 : 1.15;
+    // Round 4: everything the step touches counts, not the three fields alone -- 256^3 with a 16-cell CPML (fields + 50 MB of
+    // memory variables + 21 MB of handed-over terms) or in increment form (a fourth field) is an HBM-regime problem and
+    // wants the HBM-regime shape: 8-row tiles x 32 planes instead of 4 x 64 (CPML forward 83.3 -> 71.1, adjoint 102.7 -> 93.6
+    // us/step on one box; increment form 67.8 / 81.3 / 77.3 -> 63.7 / 76.7 / 75.4) -- once the 8-row x-border variants
+    // stopped spilling, that is: in round 3 the same choice measured 116 against 100.
+    const bool cache_resident = 3.0 * (double)g.npts * (is_f32 ? 4 : 8) + extra_bytes <= 200.0 * 1024 * 1024;
+    // (the kernels that carry extras -- the x border's recursion, the handed-over terms, the increment field -- have a
+    // longer dependency chain per plane: every CU counts for them even from HBM.  Measured at 256^3 with the CPML: 8 rows
+    // x 32 planes = 256 workgroups 71.6 / 79.8 / 93.7 us/step forward / store / adjoint, x 37 planes = 224 workgroups -- what
+    // W = 200 picks -- 81.6 / 97.1 / 100.4, round 3's 4 rows x 64 planes 84.1 / 95.6 / 103.3; at 320^3 one round of 240
+    // workgroups 188 against 248 for 320 or 160 of them)
+    const double WSAT = (cache_resident || extra_bytes > 0.0) ? 256.0 : 200.0, TY4_PENALTY = cache_resident ? 1.0 : 1.15;
     StreamTuning best{8, g.nz, 1, tile_x};
     double best_cost = 1e30;
     const int zc_min = std::min(g.nz, 16);
