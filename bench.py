@@ -423,8 +423,9 @@ def main():
                            "launch (fwi_pml.hip pml_line_t: the z and y borders' recursions, which hand their term over in "
                            "arrays compact over the border shells) + the step kernel with the x border's recursion in its "
                            "lanes, which adds the handed-over terms inside q (round 4; round 3: the step kernel + one line "
-                           "launch per axis that re-read u, C and read-modified-wrote u'); `kernel_avg_us` is the whole "
-                           "step" % w.npml,
+                           "launch per axis that re-read u, C and read-modified-wrote u'), in 8-row tiles x 32 planes -- the "
+                           "launch shape of an HBM-regime run; `kernel_avg_us` is the whole step.  This leg scatters 73 - 83 us "
+                           "from run to run on one box (DESIGN.md s.4 CPML)" % w.npml,
                            extra_bytes=mv)
         r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
         r["us_per_time_step"] = round(step_us, 3)
