@@ -170,6 +170,10 @@ def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, ex
         info = {"kernel": e.kernel_name, "set_model_ms": round(set_model_ms, 1),
                 "rccl_ranks": ex.rccl_ranks if ex is not None else None, "allreduce_check": check,
                 "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 3)}
+        pl = e.placement_info()
+        if pl[0]:  # the context placed its small arrays by measurement (3-D CPML past the cache-resident sizes)
+            info["placement"] = {"us_before": round(pl[0], 2), "us_after": round(pl[1], 2),
+                                 "offsets_MiB_psi_x_zeta_x_tz_ty": [s >> 20 for s in pl[2]]}
         return w, el, 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps), info
     finally:
         e.close()
@@ -424,13 +428,16 @@ def main():
                            "arrays compact over the border shells) + the step kernel with the x border's recursion in its "
                            "lanes, which adds the handed-over terms inside q (round 4; round 3: the step kernel + one line "
                            "launch per axis that re-read u, C and read-modified-wrote u'), in 8-row tiles x 32 planes -- the "
-                           "launch shape of an HBM-regime run; `kernel_avg_us` is the whole step.  This leg scatters 73 - 83 us "
-                           "from run to run on one box (DESIGN.md s.4 CPML)" % w.npml,
+                           "launch shape of an HBM-regime run; `kernel_avg_us` is the whole step.  Where the step kernel's seven "
+                           "arrays lie relative to each other moved this leg between 73 and 85 us from process to process; "
+                           "the context now places the four small ones by measurement at creation (`placement`; "
+                           "DESIGN.md s.4 CPML)" % w.npml,
                            extra_bytes=mv)
         r["workload"] = "3-D 256x256x256 constant velocity, O(8) + CPML npml %d, %d time steps" % (w.npml, w.nt)
         r["us_per_time_step"] = round(step_us, 3)
         r["Gpts_per_s"] = round(int(np.prod(w.shape)) / step_us / 1e3, 1)
         r["kernel"] = info["kernel"]
+        r["placement"] = info.get("placement")
         legs["cpml3d"] = r
     # measurement-only CPML legs (profiles/r04_*; never part of the default line): the gradient sweeps at 256^3 and the
     # forward sweep at 512^3, where stream_default_tuning picks the 8-row tiles

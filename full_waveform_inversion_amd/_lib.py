@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FWI_HIP_LIB") or os.path.join(_HERE, "libfwi_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 F32, F64 = 0, 1
 KERNEL_AUTO, KERNEL_POINT, KERNEL_STREAM = 0, 1, 2
 WRT_VELOCITY, WRT_SLOWNESS2 = 0, 1
@@ -70,6 +70,7 @@ SIGNATURES = {
     "fwi_comm_abort": (C.c_int, [_P]),
     "fwi_last_loop_ms": (C.c_int, [_P, C.POINTER(_D)]),
     "fwi_last_host_ms": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D)]),
+    "fwi_placement_info": (C.c_int, [_P, C.POINTER(_D), C.POINTER(_D), C.POINTER(C.c_int64)]),
     "fwi_set_launch_mode": (C.c_int, [_P, _I32]),
     "fwi_synchronize": (C.c_int, [_P]),
     "fwi_check_padding": (C.c_int, [_P, C.POINTER(_I64)]),

@@ -82,6 +82,11 @@ struct fwi_ctx {
     // pml_ty; scratch within one time step, so one pair serves every sweep of the context)
     void *pml_tz = nullptr, *pml_ty = nullptr;
     void *pml_psi[3] = {nullptr, nullptr, nullptr}, *pml_zeta[3] = {nullptr, nullptr, nullptr};
+    // Placement of the four small arrays the 3-D CPML step kernel streams beside the fields (the x border's psi and zeta,
+    // the handed-over terms tz and ty): each sits `place_shift` bytes into an allocation `place_pad` bytes longer than
+    // the array, at the position Impl::tune_placement measured as the fastest (0 = untuned; see there)
+    size_t place_pad = 0, place_shift[4] = {0, 0, 0, 0};
+    float place_us[2] = {0.f, 0.f};  // step time before / after the placement search (fwi_last_placement_us)
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
     void *pml_psi_fw[3] = {nullptr, nullptr, nullptr}, *pml_zeta_fw[3] = {nullptr, nullptr, nullptr};
@@ -1039,6 +1044,89 @@ struct Impl {
         return FWI_OK;
     }
 
+    // PLACEMENT SEARCH (3-D CPML contexts past the cache-resident sizes; fwi_create).  The step kernel of such a context
+    // streams seven arrays side by side, and how fast it runs depends on where they lie RELATIVE to each other: with every
+    // device array of a 256^3 / npml 16 context carved from one slab, moving the 10 MiB `ty` alone by 4 MiB switched the
+    // step kernel between 48.7 and 57.9 us (63.5 with everything on 64 MiB boundaries) -- same bytes by the FETCH / WRITE
+    // counters, the line launch unmoved -- and with one hipMalloc per array the draw differs per process and per box
+    // (72.9 ... 85.8 us per time step, profiles/r04_variance.log, r04_placement_probes.log).  No congruence rule we tried
+    // predicts the slow positions, so the context MEASURES: the four small arrays (x border's psi / zeta, tz, ty) are
+    // allocated with `place_pad` bytes of slack, and a coordinate search over their offsets (steps of 2 MiB) times a few
+    // time steps of the real launch sequence on zeroed fields for each candidate and keeps a position only if it is
+    // > 1 % faster twice.  ~30 candidates x ~1.5 ms: some tens of milliseconds per context, bit-identical results (the
+    // arithmetic never sees an address).  FWI_PLACEMENT_TUNE=0 is the A/B hook.
+    static int tune_placement(fwi_ctx *ctx) {
+        const GridDesc &g = ctx->gd;
+        const size_t fb = (size_t)g.ptot * sizeof(T), step = (size_t)2 << 20;
+        const int ncand = (int)(ctx->place_pad / step) + 1;
+        if (ncand < 2) return FWI_OK;
+        for (void *f : {ctx->u[0], ctx->u[1], ctx->C, ctx->vf})
+            if (f) HIPCHK(ctx, hipMemsetAsync(f, 0, fb, ctx->stream));
+        // (everything the trial steps read is zero, so everything they write is: the context is left as created)
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_psi[2], 0, ctx->pml_bytes[2] + ctx->place_pad, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_zeta[2], 0, ctx->pml_bytes[2] + ctx->place_pad, ctx->stream));
+        int rc = pml_zero(ctx);
+        if (rc) return rc;
+        hipEvent_t e0, e1;
+        HIPCHK(ctx, hipEventCreate(&e0));
+        HIPCHK(ctx, hipEventCreate(&e1));
+        const fwi_ctx::PointSet nobody;
+        auto none = [](int) -> T * { return nullptr; };
+        auto noq = [](int, const T *&p, const T *&p2) { p = p2 = nullptr; };
+        Sweep sw;
+        sw.f[0] = ctx->u[0];
+        sw.f[1] = ctx->u[1];
+        sw.v = ctx->vf;
+        int nstep = 0;
+        auto timed = [&](int n, float *us) -> int {  // n time steps of the real launch sequence, no sources, no receivers
+            HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+            const int r = run_steps(ctx, sw, nstep, 1, n, nobody, (const T *)nullptr, nullptr, (T *)nullptr, T(0), none, noq);
+            if (r) return r;
+            nstep += n;
+            HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+            HIPCHK(ctx, hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+            *us = 1e3f * ms / n;
+            return FWI_OK;
+        };
+        void **slot[4] = {&ctx->pml_psi[2], &ctx->pml_zeta[2], &ctx->pml_tz, &ctx->pml_ty};
+        float best = 0.f, t = 0.f, t2 = 0.f;
+        int n = 8;
+        // warm up (code objects' first use, clocks), then the position the context was created with -- twice, the better
+        if ((rc = timed(24, &t)) || (rc = timed(8, &t))) goto done;
+        n = std::max(4, std::min(12, (int)(1500.f / std::max(t, 1.f))));  // ~1.5 ms per trial
+        if (t > 2500.f) goto done;  // (a search would take seconds on such a grid, whose borders are a small share anyway)
+        if ((rc = timed(n, &t)) || (rc = timed(n, &t2))) goto done;
+        best = std::min(t, t2);
+        ctx->place_us[0] = ctx->place_us[1] = best;
+        for (int i : {3, 1, 2, 0}) {
+            char *const base = (char *)*slot[i] - ctx->place_shift[i];
+            size_t keep = ctx->place_shift[i];
+            for (int c = 0; c < ncand; ++c) {
+                const size_t sh = (size_t)c * step;
+                if (sh == ctx->place_shift[i]) continue;
+                *slot[i] = base + sh;
+                if ((rc = timed(n, &t))) goto done;
+                if (t < 0.99f * best) {  // confirm before believing it
+                    if ((rc = timed(n, &t2))) goto done;
+                    t = std::max(t, t2);
+                }
+                if (t < 0.99f * best) {
+                    best = t;
+                    keep = sh;
+                }
+            }
+            *slot[i] = base + keep;
+            ctx->place_shift[i] = keep;
+        }
+        ctx->place_us[1] = best;
+    done:
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
+
     // the last step's field has no following launch to ride on
     static int flush_record(fwi_ctx *ctx, Sweep &sw, const fwi_ctx::PointSet &out, T *series, T out_scale) {
         if (sw.prev_n < 0) return FWI_OK;
@@ -1520,8 +1608,9 @@ int create_impl(fwi_ctx *ctx) {
             for (int o = 0; o < 3; ++o)
                 if (o != d) cnt *= (size_t)(o == 2 ? g.cx : nd[o]);
             ctx->pml_bytes[d] = cnt * es;
-            HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d]));
-            HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d]));
+            const size_t slack = d == 2 ? ctx->place_pad : 0;  // (the x border's arrays can be moved: tune_placement)
+            HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d] + slack));
+            HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d] + slack));
             if (ctx->fused2d) {  // the set the fused launch writes (see fwi_ctx::pml_spare_psi)
                 HIPCHK(ctx, hipMalloc(&ctx->pml_spare_psi[d], ctx->pml_bytes[d]));
                 HIPCHK(ctx, hipMalloc(&ctx->pml_spare_zeta[d], ctx->pml_bytes[d]));
@@ -1553,10 +1642,10 @@ int create_impl(fwi_ctx *ctx) {
         // re-read the first vectors of the arrays and discard them, which must not be NaNs of an earlier allocation.
         const size_t bz = (size_t)pml_shell_rows(g.nz, c.npml, g.r) * g.ny * g.cx * es;
         const size_t by = (size_t)(g.nz + 1) * pml_shell_rows(g.ny, c.npml, g.r) * g.cx * es;
-        HIPCHK(ctx, hipMalloc(&ctx->pml_tz, bz));
-        HIPCHK(ctx, hipMalloc(&ctx->pml_ty, by));
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_tz, 0, bz, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_ty, 0, by, ctx->stream));
+        HIPCHK(ctx, hipMalloc(&ctx->pml_tz, bz + ctx->place_pad));
+        HIPCHK(ctx, hipMalloc(&ctx->pml_ty, by + ctx->place_pad));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_tz, 0, bz + ctx->place_pad, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_ty, 0, by + ctx->place_pad, ctx->stream));
     }
     int rc;
     if (c.dtype == FWI_F32) {
@@ -1729,6 +1818,13 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     if (getenv("FWI_DEBUG_PML"))
         fprintf(stderr, "fwi: cpml=%d fused2d=%d x-in-kernel=%d line-axes=%d (ty %d zchunk %d)\n", (int)ctx->cpml,
                 (int)ctx->fused2d, (int)ctx->xpml, ctx->pml_lines, ctx->tune.ty, ctx->tune.zchunk);
+    // 3-D CPML contexts past the cache-resident sizes place their small arrays by measurement (Impl::tune_placement).
+    // FWI_PLACEMENT_TUNE: "0" = off, "pad" = padded allocations without the search (A/B hooks), "force" = also on grids
+    // below the size threshold (tests: the oracle comparisons run small grids)
+    const char *pt = getenv("FWI_PLACEMENT_TUNE");
+    const bool place = ctx->xpml && cfg->dtype == FWI_F32 && !(pt && !strcmp(pt, "0")) &&
+                       ((double)ctx->gd.ptot * ctx->esize >= 48e6 || (pt && !strcmp(pt, "force")));
+    if (place) ctx->place_pad = (size_t)14 << 20;
     int rc = create_impl(ctx);
     if (rc == FWI_OK && ctx->inc &&
         (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
@@ -1741,6 +1837,7 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
                 rc = ctx->fail(FWI_ENOMEM, "allocating the fused 2-D buffer pair failed");
         }
     }
+    if (rc == FWI_OK && place && !(pt && !strcmp(pt, "pad"))) rc = Impl<float>::tune_placement(ctx);
     if (rc) {
         g_create_error = "fwi_create: " + ctx->err;
         fwi_destroy(ctx);
@@ -1770,6 +1867,11 @@ void fwi_destroy(fwi_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (void *v : ctx->vecs)
         if (v) (void)hipFree(v);
+    // (the four movable arrays: back to the start of their allocations)
+    if (ctx->pml_psi[2]) ctx->pml_psi[2] = (char *)ctx->pml_psi[2] - ctx->place_shift[0];
+    if (ctx->pml_zeta[2]) ctx->pml_zeta[2] = (char *)ctx->pml_zeta[2] - ctx->place_shift[1];
+    if (ctx->pml_tz) ctx->pml_tz = (char *)ctx->pml_tz - ctx->place_shift[2];
+    if (ctx->pml_ty) ctx->pml_ty = (char *)ctx->pml_ty - ctx->place_shift[3];
     for (int d = 0; d < 3; ++d)
         for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d], ctx->pml_psi_fw[d],
                         ctx->pml_zeta_fw[d], ctx->pml_spare_psi[d], ctx->pml_spare_zeta[d]})
@@ -2171,6 +2273,15 @@ int fwi_check_padding(fwi_ctx *ctx, int64_t *dirty_out) {
     HIPCHK(ctx, hipMemcpyAsync(&n, cnt, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *dirty_out = (int64_t)n;
+    return FWI_OK;
+}
+
+int fwi_placement_info(fwi_ctx *ctx, double *us_before_out, double *us_after_out, int64_t *shift_bytes_out) {
+    if (!ctx) return FWI_EINVAL;
+    if (us_before_out) *us_before_out = ctx->place_us[0];
+    if (us_after_out) *us_after_out = ctx->place_us[1];
+    if (shift_bytes_out)
+        for (int i = 0; i < 4; ++i) shift_bytes_out[i] = (int64_t)ctx->place_shift[i];
     return FWI_OK;
 }
 

@@ -328,6 +328,14 @@ class Engine:
         self._chk(self._lib.fwi_last_host_ms(self._c, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def placement_info(self):
+        """(us_before, us_after, (shift_psi_x, shift_zeta_x, shift_tz, shift_ty)) of the placement search a 3-D CPML
+        context runs at creation (include/fwi.h fwi_placement_info); zeros when the context ran none."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        sh = (C.c_int64 * 4)()
+        self._chk(self._lib.fwi_placement_info(self._c, C.byref(a), C.byref(b), sh))
+        return a.value, b.value, tuple(int(v) for v in sh)
+
     def set_launch_mode(self, mode):
         """"auto" / "stream" / "graph" from the next sweep on (an A/B on one context: same buffers, same cache state)."""
         self._chk(self._lib.fwi_set_launch_mode(self._c, _lib.LAUNCH_MODES[mode]))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FWI_ABI_VERSION 12
+#define FWI_ABI_VERSION 13
 
 enum { FWI_F32 = 0, FWI_F64 = 1 };
 
@@ -218,6 +218,11 @@ int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out);
  * (FWI_LAUNCH_GRAPH: capture + instantiation + the one graph launch), and of that the graph's capture + instantiation
  * alone (0 in stream mode).  Compared with fwi_last_loop_ms it tells whether a loop is bound by the host's launch rate. */
 int fwi_last_host_ms(fwi_ctx *ctx, double *submit_ms_out, double *graph_build_ms_out);
+/* Placement search of a 3-D CPML context (fwi_create times a few steps with the small arrays of the step kernel at
+ * different offsets inside padded allocations and keeps the fastest; results never depend on it): time per step before
+ * and after the search in microseconds (0 = no search ran for this context) and the chosen offsets in bytes of the x
+ * border's psi, zeta and the handed-over terms tz, ty.  Any out pointer may be NULL.  No reference counterpart. */
+int fwi_placement_info(fwi_ctx *ctx, double *us_before_out, double *us_after_out, int64_t *shift_bytes_out);
 /* Change fwi_config.launch_mode of a live context (takes effect with the next sweep): the A/B of stream launches against
  * hipGraph launches on ONE context, the same buffers and the same cache state (tools/graph_probe.py). */
 int fwi_set_launch_mode(fwi_ctx *ctx, int32_t mode);

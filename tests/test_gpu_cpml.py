@@ -201,12 +201,15 @@ def test_cpml_configs1_at_full_size_vs_c_oracle(gpu):
     _cpml_vs_c_oracle(workloads.cfg2(1.0), 1000, 3.14159 * 15.0, "step2d_fused")
 
 
-@pytest.mark.parametrize("stream_ty,kw", [(None, {}), ("8", {}), ("8", {"update_form": "increment"})])
+@pytest.mark.parametrize("stream_ty,kw", [(None, {}), ("8", {}), ("8", {"update_form": "increment"}),
+                                          ("place", {}), ("place", {"update_form": "increment"})])
 def test_cpml_3d_lines_and_lanes_at_size_vs_c_oracle(gpu, monkeypatch, stream_ty, kw):
     """3-D 160^3 heterogeneous model, npml 16, 400 steps: the x border in step3d_stream's lanes, the z and y borders'
     term from the line launch (several workgroup tiles, all z chunks, two segments per line) against the C oracle --
     with the tuned tile shape and with the 8-row tiles of the HBM-regime grids."""
-    if stream_ty:
+    if stream_ty == "place":  # the placement search (fwi_api.hip tune_placement) forced onto this grid: same numbers
+        monkeypatch.setenv("FWI_PLACEMENT_TUNE", "force")
+    elif stream_ty:
         monkeypatch.setenv("FWI_STREAM_TY", stream_ty)
     w = workloads.cfg5(0.625, nshots=1)
     w.npml = 16

@@ -34,9 +34,11 @@ def main():
         for r in range(a.shots):
             e.forward(None, (w.src_idx[:1], wav), w.rec_idx, save=False)
             t.append(round(1e3 * e.last_loop_ms() / w.nt, 2))
+        pl = e.placement_info() if hasattr(e, "placement_info") else None
         e.close()
         rows.append(t)
-        print("context %d: us/step per shot %s" % (i, t), flush=True)
+        print("context %d: us/step per shot %s%s" % (i, t, "" if not pl or not pl[0] else
+              "  placement search %.1f -> %.1f us, offsets MiB %s" % (pl[0], pl[1], [s >> 20 for s in pl[2]])), flush=True)
     print(json.dumps({"probe": "variance", "abc": a.abc, "shape": list(w.shape), "us_per_step": rows}))
 
 
