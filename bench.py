@@ -171,9 +171,9 @@ def run_leg(make_workload, device, steps, warmup, grad=False, engine_kw=None, ex
                 "rccl_ranks": ex.rccl_ranks if ex is not None else None, "allreduce_check": check,
                 "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 3)}
         pl = e.placement_info()
-        if pl[0]:  # the context placed its small arrays by measurement (3-D CPML past the cache-resident sizes)
+        if pl[0]:  # the context placed some of its arrays by measurement (3-D CPML / increment form; fwi_placement_info)
             info["placement"] = {"us_before": round(pl[0], 2), "us_after": round(pl[1], 2),
-                                 "offsets_MiB_psi_x_zeta_x_tz_ty": [s >> 20 for s in pl[2]]}
+                                 "offsets_MiB": [s >> 20 for s in pl[2][:5]]}
         return w, el, 1e3 * float(np.mean(loop_ms)) / (w.nt * sweeps), info
     finally:
         e.close()
@@ -358,6 +358,8 @@ def main():
         r["rccl_ranks"] = info["rccl_ranks"]
         r["allreduce_ms"] = info["allreduce_ms"]
         r["allreduce_check"] = info["allreduce_check"]
+        if info.get("placement"):
+            r["placement"] = info["placement"]
         legs[name] = r
 
     # the gradient leg runs on every rank when there is an exchange to time (N > 1, or the forced rehearsal)

@@ -85,8 +85,21 @@ struct fwi_ctx {
     // Placement of the four small arrays the 3-D CPML step kernel streams beside the fields (the x border's psi and zeta,
     // the handed-over terms tz and ty): each sits `place_shift` bytes into an allocation `place_pad` bytes longer than
     // the array, at the position Impl::tune_placement measured as the fastest (0 = untuned; see there)
-    size_t place_pad = 0, place_shift[4] = {0, 0, 0, 0};
-    float place_us[2] = {0.f, 0.f};  // step time before / after the placement search (fwi_last_placement_us)
+    // (place_kind 2, increment-form contexts without CPML: the fields v and C instead -- worth 1.5 - 3 % there, the
+    // per-process spread of that form is not theirs to fix; the u buffers change roles with others and stay put)
+    int place_kind = 0;
+    size_t place_pad = 0;
+    int nmov = 0;                 // the movable arrays in search order: the member that points at them, their size,
+    void **mov_slot[8] = {};      // how far into their allocation they currently sit
+    size_t mov_bytes[8] = {}, mov_shift[8] = {};
+    void movable(void **slot, size_t bytes) {
+        if (place_pad && nmov < 8) {
+            mov_slot[nmov] = slot;
+            mov_bytes[nmov] = bytes;
+            mov_shift[nmov++] = 0;
+        }
+    }
+    float place_us[2] = {0.f, 0.f};  // step time before / after the placement search (fwi_placement_info)
     // with checkpointing: the memory variables of the forward recomputation (the running adjoint sweep keeps its own
     // in the set above) and, per snapshot, a copy of the forward set (psi then zeta, axis by axis)
     void *pml_psi_fw[3] = {nullptr, nullptr, nullptr}, *pml_zeta_fw[3] = {nullptr, nullptr, nullptr};
@@ -1059,12 +1072,12 @@ struct Impl {
         const GridDesc &g = ctx->gd;
         const size_t fb = (size_t)g.ptot * sizeof(T), step = (size_t)2 << 20;
         const int ncand = (int)(ctx->place_pad / step) + 1;
-        if (ncand < 2) return FWI_OK;
+        if (ncand < 2 || ctx->nmov == 0) return FWI_OK;
+        // everything the trial steps read is zero, so everything they write is: the context is left as created
         for (void *f : {ctx->u[0], ctx->u[1], ctx->C, ctx->vf})
             if (f) HIPCHK(ctx, hipMemsetAsync(f, 0, fb, ctx->stream));
-        // (everything the trial steps read is zero, so everything they write is: the context is left as created)
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_psi[2], 0, ctx->pml_bytes[2] + ctx->place_pad, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_zeta[2], 0, ctx->pml_bytes[2] + ctx->place_pad, ctx->stream));
+        for (int i = 0; i < ctx->nmov; ++i)  // (the movable arrays: the whole allocation, whichever position wins)
+            HIPCHK(ctx, hipMemsetAsync(*ctx->mov_slot[i], 0, ctx->mov_bytes[i] + ctx->place_pad, ctx->stream));
         int rc = pml_zero(ctx);
         if (rc) return rc;
         hipEvent_t e0, e1;
@@ -1090,7 +1103,6 @@ struct Impl {
             *us = 1e3f * ms / n;
             return FWI_OK;
         };
-        void **slot[4] = {&ctx->pml_psi[2], &ctx->pml_zeta[2], &ctx->pml_tz, &ctx->pml_ty};
         float best = 0.f, t = 0.f, t2 = 0.f;
         int n = 8;
         // warm up (code objects' first use, clocks), then the position the context was created with -- twice, the better
@@ -1100,13 +1112,14 @@ struct Impl {
         if ((rc = timed(n, &t)) || (rc = timed(n, &t2))) goto done;
         best = std::min(t, t2);
         ctx->place_us[0] = ctx->place_us[1] = best;
-        for (int i : {3, 1, 2, 0}) {
-            char *const base = (char *)*slot[i] - ctx->place_shift[i];
-            size_t keep = ctx->place_shift[i];
+        for (int i = 0; i < ctx->nmov; ++i) {
+            void **const slot = ctx->mov_slot[i];
+            char *const base = (char *)*slot - ctx->mov_shift[i];
+            size_t keep = ctx->mov_shift[i];
             for (int c = 0; c < ncand; ++c) {
                 const size_t sh = (size_t)c * step;
-                if (sh == ctx->place_shift[i]) continue;
-                *slot[i] = base + sh;
+                if (sh == ctx->mov_shift[i]) continue;
+                *slot = base + sh;
                 if ((rc = timed(n, &t))) goto done;
                 if (t < 0.99f * best) {  // confirm before believing it
                     if ((rc = timed(n, &t2))) goto done;
@@ -1117,8 +1130,8 @@ struct Impl {
                     keep = sh;
                 }
             }
-            *slot[i] = base + keep;
-            ctx->place_shift[i] = keep;
+            *slot = base + keep;
+            ctx->mov_shift[i] = keep;
         }
         ctx->place_us[1] = best;
     done:
@@ -1572,12 +1585,14 @@ int create_impl(fwi_ctx *ctx) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    const size_t fslack = ctx->place_kind == 2 ? ctx->place_pad : 0;  // (tune_placement may move C; the u buffers
+                                                                       // change roles with others and stay where they are)
     for (int i = 0; i < 2; ++i) {
         HIPCHK(ctx, hipMalloc(&ctx->u[i], (size_t)g.ptot * es));
         HIPCHK(ctx, hipMemsetAsync(ctx->u[i], 0, (size_t)g.ptot * es, ctx->stream));
     }
-    HIPCHK(ctx, hipMalloc(&ctx->C, (size_t)g.ptot * es));
-    HIPCHK(ctx, hipMemsetAsync(ctx->C, 0, (size_t)g.ptot * es, ctx->stream));
+    HIPCHK(ctx, hipMalloc(&ctx->C, (size_t)g.ptot * es + fslack));
+    HIPCHK(ctx, hipMemsetAsync(ctx->C, 0, (size_t)g.ptot * es + fslack, ctx->stream));
     HIPCHK(ctx, hipMalloc(&ctx->c_dev, (size_t)g.npts * es));
     HIPCHK(ctx, hipMalloc(&ctx->g_acc, (size_t)g.npts * es));
     HIPCHK(ctx, hipMemsetAsync(ctx->g_acc, 0, (size_t)g.npts * es, ctx->stream));
@@ -1608,7 +1623,7 @@ int create_impl(fwi_ctx *ctx) {
             for (int o = 0; o < 3; ++o)
                 if (o != d) cnt *= (size_t)(o == 2 ? g.cx : nd[o]);
             ctx->pml_bytes[d] = cnt * es;
-            const size_t slack = d == 2 ? ctx->place_pad : 0;  // (the x border's arrays can be moved: tune_placement)
+            const size_t slack = (d == 2 && ctx->place_kind == 1) ? ctx->place_pad : 0;  // (the x border's arrays can be moved: tune_placement)
             HIPCHK(ctx, hipMalloc(&ctx->pml_psi[d], ctx->pml_bytes[d] + slack));
             HIPCHK(ctx, hipMalloc(&ctx->pml_zeta[d], ctx->pml_bytes[d] + slack));
             if (ctx->fused2d) {  // the set the fused launch writes (see fwi_ctx::pml_spare_psi)
@@ -1642,10 +1657,17 @@ int create_impl(fwi_ctx *ctx) {
         // re-read the first vectors of the arrays and discard them, which must not be NaNs of an earlier allocation.
         const size_t bz = (size_t)pml_shell_rows(g.nz, c.npml, g.r) * g.ny * g.cx * es;
         const size_t by = (size_t)(g.nz + 1) * pml_shell_rows(g.ny, c.npml, g.r) * g.cx * es;
-        HIPCHK(ctx, hipMalloc(&ctx->pml_tz, bz + ctx->place_pad));
-        HIPCHK(ctx, hipMalloc(&ctx->pml_ty, by + ctx->place_pad));
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_tz, 0, bz + ctx->place_pad, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->pml_ty, 0, by + ctx->place_pad, ctx->stream));
+        const size_t slack = ctx->place_kind == 1 ? ctx->place_pad : 0;
+        HIPCHK(ctx, hipMalloc(&ctx->pml_tz, bz + slack));
+        HIPCHK(ctx, hipMalloc(&ctx->pml_ty, by + slack));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_tz, 0, bz + slack, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->pml_ty, 0, by + slack, ctx->stream));
+        if (ctx->place_kind == 1) {  // search order: the positions that decided the slab experiments first
+            ctx->movable(&ctx->pml_ty, by);
+            ctx->movable(&ctx->pml_zeta[2], ctx->pml_bytes[2]);
+            ctx->movable(&ctx->pml_tz, bz);
+            ctx->movable(&ctx->pml_psi[2], ctx->pml_bytes[2]);
+        }
     }
     int rc;
     if (c.dtype == FWI_F32) {
@@ -1822,14 +1844,20 @@ int fwi_create(const fwi_config *cfg, fwi_ctx **out) {
     // FWI_PLACEMENT_TUNE: "0" = off, "pad" = padded allocations without the search (A/B hooks), "force" = also on grids
     // below the size threshold (tests: the oracle comparisons run small grids)
     const char *pt = getenv("FWI_PLACEMENT_TUNE");
-    const bool place = ctx->xpml && cfg->dtype == FWI_F32 && !(pt && !strcmp(pt, "0")) &&
-                       ((double)ctx->gd.ptot * ctx->esize >= 48e6 || (pt && !strcmp(pt, "force")));
+    const bool place_on = cfg->dtype == FWI_F32 && cfg->ndim == 3 && ctx->kernel == K_STREAM && !(pt && !strcmp(pt, "0")) &&
+                          ((double)ctx->gd.ptot * ctx->esize >= 48e6 || (pt && !strcmp(pt, "force")));
+    if (place_on && ctx->xpml) ctx->place_kind = 1;
+    else if (place_on && ctx->inc && !ctx->cpml) ctx->place_kind = 2;
+    const bool place = ctx->place_kind != 0;
     if (place) ctx->place_pad = (size_t)14 << 20;
     int rc = create_impl(ctx);
+    const size_t vslack = ctx->place_kind ? ctx->place_pad : 0;
     if (rc == FWI_OK && ctx->inc &&
-        (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
-         hipMemset(ctx->vf, 0, (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess))
+        (hipMalloc(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize + vslack) != hipSuccess ||
+         hipMemset(ctx->vf, 0, (size_t)ctx->gd.ptot * ctx->esize + vslack) != hipSuccess))
         rc = ctx->fail(FWI_ENOMEM, "allocating the increment field failed");
+    if (rc == FWI_OK && ctx->place_kind && ctx->inc) ctx->movable(&ctx->vf, (size_t)ctx->gd.ptot * ctx->esize);
+    if (rc == FWI_OK && ctx->place_kind == 2) ctx->movable(&ctx->C, (size_t)ctx->gd.ptot * ctx->esize);
     if (rc == FWI_OK && (ctx->fused2d || ctx->pair3d)) {
         for (int i = 0; i < 2 && rc == FWI_OK; ++i) {
             if (hipMalloc(&ctx->fx[i], (size_t)ctx->gd.ptot * ctx->esize) != hipSuccess ||
@@ -1868,10 +1896,8 @@ void fwi_destroy(fwi_ctx *ctx) {
     for (void *v : ctx->vecs)
         if (v) (void)hipFree(v);
     // (the four movable arrays: back to the start of their allocations)
-    if (ctx->pml_psi[2]) ctx->pml_psi[2] = (char *)ctx->pml_psi[2] - ctx->place_shift[0];
-    if (ctx->pml_zeta[2]) ctx->pml_zeta[2] = (char *)ctx->pml_zeta[2] - ctx->place_shift[1];
-    if (ctx->pml_tz) ctx->pml_tz = (char *)ctx->pml_tz - ctx->place_shift[2];
-    if (ctx->pml_ty) ctx->pml_ty = (char *)ctx->pml_ty - ctx->place_shift[3];
+    for (int i = 0; i < ctx->nmov; ++i)
+        if (*ctx->mov_slot[i]) *ctx->mov_slot[i] = (char *)*ctx->mov_slot[i] - ctx->mov_shift[i];
     for (int d = 0; d < 3; ++d)
         for (void *q : {ctx->pml_psi[d], ctx->pml_zeta[d], ctx->pml_a[d], ctx->pml_b[d], ctx->pml_psi_fw[d],
                         ctx->pml_zeta_fw[d], ctx->pml_spare_psi[d], ctx->pml_spare_zeta[d]})
@@ -2281,7 +2307,7 @@ int fwi_placement_info(fwi_ctx *ctx, double *us_before_out, double *us_after_out
     if (us_before_out) *us_before_out = ctx->place_us[0];
     if (us_after_out) *us_after_out = ctx->place_us[1];
     if (shift_bytes_out)
-        for (int i = 0; i < 4; ++i) shift_bytes_out[i] = (int64_t)ctx->place_shift[i];
+        for (int i = 0; i < 8; ++i) shift_bytes_out[i] = i < ctx->nmov ? (int64_t)ctx->mov_shift[i] : 0;
     return FWI_OK;
 }
 

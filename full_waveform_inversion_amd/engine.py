@@ -329,10 +329,11 @@ class Engine:
         return a.value, b.value
 
     def placement_info(self):
-        """(us_before, us_after, (shift_psi_x, shift_zeta_x, shift_tz, shift_ty)) of the placement search a 3-D CPML
-        context runs at creation (include/fwi.h fwi_placement_info); zeros when the context ran none."""
+        """(us_before, us_after, shifts) of the placement search a 3-D CPML or increment-form context runs at creation
+        (include/fwi.h fwi_placement_info; shifts = bytes of the movable arrays in search order, then zeros); all zeros
+        when the context ran none."""
         a, b = C.c_double(0.0), C.c_double(0.0)
-        sh = (C.c_int64 * 4)()
+        sh = (C.c_int64 * 8)()
         self._chk(self._lib.fwi_placement_info(self._c, C.byref(a), C.byref(b), sh))
         return a.value, b.value, tuple(int(v) for v in sh)
 

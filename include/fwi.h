@@ -218,10 +218,12 @@ int fwi_last_loop_ms(fwi_ctx *ctx, double *ms_out);
  * (FWI_LAUNCH_GRAPH: capture + instantiation + the one graph launch), and of that the graph's capture + instantiation
  * alone (0 in stream mode).  Compared with fwi_last_loop_ms it tells whether a loop is bound by the host's launch rate. */
 int fwi_last_host_ms(fwi_ctx *ctx, double *submit_ms_out, double *graph_build_ms_out);
-/* Placement search of a 3-D CPML context (fwi_create times a few steps with the small arrays of the step kernel at
- * different offsets inside padded allocations and keeps the fastest; results never depend on it): time per step before
- * and after the search in microseconds (0 = no search ran for this context) and the chosen offsets in bytes of the x
- * border's psi, zeta and the handed-over terms tz, ty.  Any out pointer may be NULL.  No reference counterpart. */
+/* Placement search (3-D fp32 stream contexts with the convolutional PML or in increment form, past the cache-resident
+ * sizes): fwi_create times a few steps with some of the context's arrays at different offsets inside padded
+ * allocations and keeps the fastest; results never depend on it.  Time per step before and after the search in
+ * microseconds (0 = no search ran for this context) and, into shift_bytes_out[8], the chosen offsets in bytes of the
+ * movable arrays in search order (CPML: ty, zeta_x, tz, psi_x, then v in increment form; increment form without CPML:
+ * v, C; unused entries 0).  Any out pointer may be NULL.  No reference counterpart. */
 int fwi_placement_info(fwi_ctx *ctx, double *us_before_out, double *us_after_out, int64_t *shift_bytes_out);
 /* Change fwi_config.launch_mode of a live context (takes effect with the next sweep): the A/B of stream launches against
  * hipGraph launches on ONE context, the same buffers and the same cache state (tools/graph_probe.py). */

@@ -38,7 +38,7 @@ def main():
         e.close()
         rows.append(t)
         print("context %d: us/step per shot %s%s" % (i, t, "" if not pl or not pl[0] else
-              "  placement search %.1f -> %.1f us, offsets MiB %s" % (pl[0], pl[1], [s >> 20 for s in pl[2]])), flush=True)
+              "  placement search %.1f -> %.1f us, offsets MiB %s" % (pl[0], pl[1], [s >> 20 for s in pl[2][:5]])), flush=True)
     print(json.dumps({"probe": "variance", "abc": a.abc, "shape": list(w.shape), "us_per_step": rows}))
 
 
