@@ -1092,6 +1092,7 @@ struct Impl {
         sw.v = ctx->vf;
         int nstep = 0;
         auto timed = [&](int n, float *us) -> int {  // n time steps of the real launch sequence, no sources, no receivers
+            sw.v = ctx->vf;  // (a movable array itself in increment form)
             HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
             const int r = run_steps(ctx, sw, nstep, 1, n, nobody, (const T *)nullptr, nullptr, (T *)nullptr, T(0), none, noq);
             if (r) return r;
@@ -1112,28 +1113,32 @@ struct Impl {
         if ((rc = timed(n, &t)) || (rc = timed(n, &t2))) goto done;
         best = std::min(t, t2);
         ctx->place_us[0] = ctx->place_us[1] = best;
-        for (int i = 0; i < ctx->nmov; ++i) {
+        for (int i = 0; i < ctx->nmov && !rc; ++i) {
             void **const slot = ctx->mov_slot[i];
             char *const base = (char *)*slot - ctx->mov_shift[i];
             size_t keep = ctx->mov_shift[i];
-            for (int c = 0; c < ncand; ++c) {
+            for (int c = 0; c < ncand && !rc; ++c) {
                 const size_t sh = (size_t)c * step;
-                if (sh == ctx->mov_shift[i]) continue;
+                if (sh == keep) continue;
                 *slot = base + sh;
-                if ((rc = timed(n, &t))) goto done;
-                if (t < 0.99f * best) {  // confirm before believing it
-                    if ((rc = timed(n, &t2))) goto done;
-                    t = std::max(t, t2);
-                }
-                if (t < 0.99f * best) {
+                if ((rc = timed(n, &t)) || t >= 0.99f * best) continue;
+                // a candidate that looks > 1 % faster: once more, then the incumbent again (the clock drifts over a
+                // search), and only a candidate that beats both readings is kept
+                if ((rc = timed(n, &t2))) continue;
+                t = std::max(t, t2);
+                *slot = base + keep;
+                if ((rc = timed(n, &t2))) continue;
+                if (t < 0.99f * t2) {
                     best = t;
                     keep = sh;
+                } else {
+                    best = t2;
                 }
             }
-            *slot = base + keep;
+            *slot = base + keep;  // (also on an error: the slot and its recorded shift always agree)
             ctx->mov_shift[i] = keep;
         }
-        ctx->place_us[1] = best;
+        if (!rc) ctx->place_us[1] = best;
     done:
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
