@@ -21,10 +21,13 @@ def main():
     ap.add_argument("--abc", default="cpml")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--update-form", default="standard")
+    ap.add_argument("--zero-wavelet", action="store_true", help="source amplitude 0: the sweep moves all-zero fields")
     a = ap.parse_args()
     w = workloads.cfg4(a.scale, npml=16)
     w.nt = a.nt
     wav = w.wavelet(np.float32)
+    if a.zero_wavelet:
+        wav = np.zeros_like(wav)
     rows = []
     for i in range(a.contexts):
         e = Engine(w.shape, w.h, w.dt, w.nt, order=w.order, npml=w.npml, abc=a.abc, update_form=a.update_form,
